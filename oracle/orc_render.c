@@ -1,0 +1,256 @@
+/*
+ * orc_render.c -- camera rays, textures, materials and the path loop of the
+ * CPU oracle (test infrastructure only; see orc_math.h).
+ *
+ * Camera: colour/src/camera/perspective.rs:54-78, geometry/src/sampling.rs:4-22
+ * (second branch uses x / y), geometry/src/transform.rs:530-552.
+ * Next-ray origin: shapes/src/interaction.rs:86-99, geometry/src/lib.rs:129-151.
+ * RNG: geometry/src/rng.rs.  Materials, textures, Perlin noise and constant
+ * media have no code in the reference; they follow the schema of the scene
+ * files under test/ (Lambertian / Metallic / Dielectric / DiffuseLight,
+ * Solid / Checker / Image / Noise, Volume) and are specified here.
+ */
+#include "orc_internal.h"
+
+#define G3 orc_gamma(3)
+
+v3 orc_offset_origin(v3 p, v3 err, v3 n, v3 w) { /* lib.rs:129-151 */
+    float d = v3_dot(v3_abs(n), err);
+    v3 off = v3_scale(n, d);
+    if (v3_dot(n, w) < 0.0f) off = v3_neg(off);
+    v3 po = v3_add(p, off);
+    if (off.x > 0.0f) po.x = next_float_up(po.x); else if (off.x < 0.0f) po.x = next_float_down(po.x);
+    if (off.y > 0.0f) po.y = next_float_up(po.y); else if (off.y < 0.0f) po.y = next_float_down(po.y);
+    if (off.z > 0.0f) po.z = next_float_up(po.z); else if (off.z < 0.0f) po.z = next_float_down(po.z);
+    return po;
+}
+
+/* concentric_sample_disk, sampling.rs:4-22 */
+static void concentric_disk(float u, float v, float *dx, float *dy) {
+    float ox = u * 2.0f - 1.0f, oy = v * 2.0f - 1.0f;
+    if (ox == 0.0f && oy == 0.0f) { *dx = 0.0f; *dy = 0.0f; return; }
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) {
+        r = ox;
+        theta = 0.785398163f * (oy / ox);
+    } else {
+        r = oy;
+        theta = 1.57079637f - 0.785398163f * (ox / oy);
+    }
+    *dx = orc_cos(theta) * r;
+    *dy = orc_sin(theta) * r;
+}
+
+void orc_camera_ray(const rt_camera *cam, float fx, float fy, float lu, float lv, float tu,
+                    rt_ray *out) {
+    const float *m = cam->raster_to_camera; /* Point3 * Transform, transform.rs:332-349 */
+    float xp = m[0] * fx + m[1] * fy + m[2] * 0.0f + m[3];
+    float yp = m[4] * fx + m[5] * fy + m[6] * 0.0f + m[7];
+    float zp = m[8] * fx + m[9] * fy + m[10] * 0.0f + m[11];
+    float wp = m[12] * fx + m[13] * fy + m[14] * 0.0f + m[15];
+    v3 pc = v3_make(xp, yp, zp);
+    if (wp != 1.0f) pc = v3_div(pc, wp);
+    v3 o = v3_make(0.0f, 0.0f, 0.0f);
+    v3 d = v3_norm(pc);
+    if (cam->lens_radius > 0.0f) { /* perspective.rs:60-69 */
+        float lx, ly;
+        concentric_disk(lu, lv, &lx, &ly);
+        lx *= cam->lens_radius;
+        ly *= cam->lens_radius;
+        float ft = cam->focal_distance / d.z;
+        v3 focus = v3_scale(d, ft);
+        o = v3_make(lx, ly, 0.0f);
+        d = v3_norm(v3_sub(focus, o));
+    }
+    /* lerp(t, open, close), lib.rs:85-87 */
+    float time = (1.0f - tu) * cam->shutter_open + tu * cam->shutter_close;
+    /* ray * camera_to_world, transform.rs:530-552 */
+    const float *c = cam->camera_to_world;
+    v3 wo = v3_make(c[0] * o.x + c[1] * o.y + c[2] * o.z + c[3],
+                    c[4] * o.x + c[5] * o.y + c[6] * o.z + c[7],
+                    c[8] * o.x + c[9] * o.y + c[10] * o.z + c[11]);
+    v3 oerr = v3_scale(
+        v3_make(fabsf(c[0] * o.x) + fabsf(c[1] * o.y) + fabsf(c[2] * o.z) + fabsf(c[3]),
+                fabsf(c[4] * o.x) + fabsf(c[5] * o.y) + fabsf(c[6] * o.z) + fabsf(c[7]),
+                fabsf(c[8] * o.x) + fabsf(c[9] * o.y) + fabsf(c[10] * o.z) + fabsf(c[11])),
+        G3);
+    v3 wd = v3_make(c[0] * d.x + c[1] * d.y + c[2] * d.z, c[4] * d.x + c[5] * d.y + c[6] * d.z,
+                    c[8] * d.x + c[9] * d.y + c[10] * d.z);
+    float len_sq = v3_dot(wd, wd);
+    float t_max = INFINITY;
+    if (len_sq > 0.0f) {
+        float dt = v3_dot(v3_abs(wd), oerr) / len_sq;
+        wo = v3_add(wo, v3_scale(wd, dt));
+        t_max -= dt;
+    }
+    out->o[0] = wo.x; out->o[1] = wo.y; out->o[2] = wo.z;
+    out->d[0] = wd.x; out->d[1] = wd.y; out->d[2] = wd.z;
+    out->t_max = t_max;
+    out->time = time;
+}
+
+/* path p = pixel * spp + sample; its PCG32 sequence index is seed * 2^32 + p.
+ * Sample order: film x, film y, time, lens u, lens v. */
+void orc_path_setup(const rt_camera *cam, const rt_render_opts *opts, uint64_t path, orc_rng *rng,
+                    rt_ray *ray) {
+    uint64_t pixel = path / opts->spp;
+    uint32_t px = (uint32_t)(pixel % opts->width), py = (uint32_t)(pixel / opts->width);
+    orc_rng_seq(rng, (opts->seed << 32) + path);
+    float u1 = orc_rng_f(rng), u2 = orc_rng_f(rng), ut = orc_rng_f(rng);
+    float l1 = orc_rng_f(rng), l2 = orc_rng_f(rng);
+    orc_camera_ray(cam, (float)px + u1, (float)py + u2, l1, l2, ut, ray);
+}
+
+/* ---- textures ---------------------------------------------------------------- */
+static float perlin_noise(const orc_scene *s, v3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = u * u * (3.0f - 2.0f * u);
+    float vv = v * v * (3.0f - 2.0f * v);
+    float ww = w * w * (3.0f - 2.0f * w);
+    const int32_t *px = s->perlin_perm, *py = s->perlin_perm + 256, *pz = s->perlin_perm + 512;
+    float accum = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255];
+                const float *c = s->perlin_vec + 3 * idx;
+                float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+                float dot = c[0] * wx + c[1] * wy + c[2] * wz;
+                float fi = di ? uu : 1.0f - uu;
+                float fj = dj ? vv : 1.0f - vv;
+                float fk = dk ? ww : 1.0f - ww;
+                accum += fi * fj * fk * dot;
+            }
+    return accum;
+}
+static float perlin_turb(const orc_scene *s, v3 p) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * perlin_noise(s, p);
+        weight *= 0.5f;
+        p = v3_scale(p, 2.0f);
+    }
+    return fabsf(accum);
+}
+
+static v3 texture_value(const orc_scene *s, uint32_t tex, float u, float v, v3 p) {
+    for (int level = 0; level < 8; level++) {
+        const rt_texture *t = &s->textures[tex];
+        switch (t->kind) {
+        case RT_TEX_CHECKER: {
+            float sines = orc_sin(t->scale * p.x) * orc_sin(t->scale * p.y) * orc_sin(t->scale * p.z);
+            tex = sines < 0.0f ? t->a : t->b;
+            continue;
+        }
+        case RT_TEX_CHECKER_UV: {
+            int cu = (int)floorf(u * t->scale), cv = (int)floorf(v * t->scale);
+            tex = ((cu + cv) & 1) ? t->a : t->b;
+            continue;
+        }
+        case RT_TEX_IMAGE: {
+            const rt_image *im = &s->images[t->a];
+            float uc = orc_clamp(u, 0.0f, 1.0f), vc = 1.0f - orc_clamp(v, 0.0f, 1.0f);
+            int i = (int)(uc * (float)im->w), j = (int)(vc * (float)im->h);
+            if (i >= (int)im->w) i = (int)im->w - 1;
+            if (j >= (int)im->h) j = (int)im->h - 1;
+            const uint8_t *px = im->rgb8 + 3 * ((size_t)j * im->w + (size_t)i);
+            const float sc = 1.0f / 255.0f;
+            return v3_make((float)px[0] * sc, (float)px[1] * sc, (float)px[2] * sc);
+        }
+        case RT_TEX_NOISE: {
+            float g = 0.5f * (1.0f + orc_sin(t->scale * p.z + 10.0f * perlin_turb(s, p)));
+            return v3_make(g, g, g);
+        }
+        default: return v3_make(t->rgb[0], t->rgb[1], t->rgb[2]);
+        }
+    }
+    return v3_make(0.0f, 0.0f, 0.0f);
+}
+
+/* ---- scattering --------------------------------------------------------------- */
+static v3 random_in_unit_sphere(orc_rng *rng) {
+    for (;;) {
+        float x = 2.0f * orc_rng_f(rng) - 1.0f;
+        float y = 2.0f * orc_rng_f(rng) - 1.0f;
+        float z = 2.0f * orc_rng_f(rng) - 1.0f;
+        if (x * x + y * y + z * z < 1.0f) return v3_make(x, y, z);
+    }
+}
+static v3 reflect(v3 v, v3 n) { return v3_sub(v, v3_scale(n, 2.0f * v3_dot(v, n))); }
+
+/* One path.  Returns the number of ray segments traced. */
+uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
+                        uint64_t path, float rgb[3], uint64_t counters[9]) {
+    orc_rng rng;
+    rt_ray ray;
+    orc_path_setup(cam, opts, path, &rng, &ray);
+    v3 beta = v3_make(1.0f, 1.0f, 1.0f);
+    v3 L = v3_make(0.0f, 0.0f, 0.0f);
+    uint32_t segments = 0;
+    for (uint32_t depth = 0; depth < opts->max_depth; depth++) {
+        orc_surf h;
+        segments++;
+        if (!orc_closest(s, &ray, &h, counters)) {
+            L = v3_make(beta.x * s->background[0], beta.y * s->background[1],
+                        beta.z * s->background[2]);
+            break;
+        }
+        v3 d = v3_make(ray.d[0], ray.d[1], ray.d[2]);
+        int front = v3_dot(d, h.n) < 0.0f;
+        v3 nf = front ? h.n : v3_neg(h.n);
+        const rt_material *m = &s->materials[s->prims[h.prim].material];
+        v3 dir;
+        if (m->kind == RT_MAT_DIFFUSE_LIGHT) {
+            v3 e = texture_value(s, m->texture, h.u, h.v, h.p);
+            L = v3_make(beta.x * e.x, beta.y * e.y, beta.z * e.z);
+            break;
+        } else if (m->kind == RT_MAT_LAMBERTIAN) {
+            v3 r = random_in_unit_sphere(&rng);
+            dir = v3_add(nf, r);
+            if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = nf;
+            dir = v3_norm(dir);
+            v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
+            beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+        } else if (m->kind == RT_MAT_METALLIC) {
+            v3 r = random_in_unit_sphere(&rng);
+            dir = v3_add(reflect(d, nf), v3_scale(r, m->fuzz));
+            if (!(v3_dot(dir, nf) > 0.0f)) break; /* absorbed */
+            dir = v3_norm(dir);
+            v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
+            beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+        } else if (m->kind == RT_MAT_DIELECTRIC) {
+            float ratio = front ? 1.0f / m->ior : m->ior;
+            float cos_t = sel_min(v3_dot(v3_neg(d), nf), 1.0f);
+            float sin_t = sqrtf(1.0f - cos_t * cos_t);
+            int reflect_it = ratio * sin_t > 1.0f;
+            if (!reflect_it) { /* Schlick */
+                float r0 = (1.0f - ratio) / (1.0f + ratio);
+                r0 = r0 * r0;
+                float c = 1.0f - cos_t;
+                float refl = r0 + (1.0f - r0) * (c * c * c * c * c);
+                reflect_it = refl > orc_rng_f(&rng);
+            }
+            if (reflect_it) {
+                dir = reflect(d, nf);
+            } else {
+                v3 perp = v3_scale(v3_add(d, v3_scale(nf, cos_t)), ratio);
+                float k = 1.0f - v3_dot(perp, perp);
+                v3 par = v3_scale(nf, -sqrtf(fabsf(k)));
+                dir = v3_add(perp, par);
+            }
+            dir = v3_norm(dir);
+        } else { /* RT_MAT_ISOTROPIC */
+            dir = v3_norm(random_in_unit_sphere(&rng));
+            v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
+            beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+        }
+        v3 no = orc_offset_origin(h.p, h.perr, h.n, dir); /* spawn_ray, interaction.rs:86-99 */
+        ray.o[0] = no.x; ray.o[1] = no.y; ray.o[2] = no.z;
+        ray.d[0] = dir.x; ray.d[1] = dir.y; ray.d[2] = dir.z;
+        ray.t_max = INFINITY;
+    }
+    rgb[0] = L.x; rgb[1] = L.y; rgb[2] = L.z;
+    return segments;
+}

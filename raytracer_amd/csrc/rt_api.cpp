@@ -1,0 +1,801 @@
+// rt_api.cpp -- host runtime behind the C ABI of include/rt355.h: scene
+// construction (BVH::new, shapes/src/bvh.rs:108-121), the one-time upload of
+// the flattened tree and primitive tables to HBM, batch intersection entry
+// points and the wavefront render loop.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.hpp"
+#include "rt_device.hpp"
+#include "rt_kernels.hpp"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                 \
+    } while (0)
+
+using rt::Aabb;
+
+// ---- host arithmetic for primitive bounds (same expressions as the kernels) ----------------
+struct H3 {
+    float x, y, z;
+};
+H3 h_point(const float *m, H3 p) { // transform.rs:335-341
+    return H3{m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+float sel_lo(float a, float b) { return b < a ? b : a; }
+float sel_hi(float a, float b) { return b > a ? b : a; }
+Aabb grow(Aabb b, H3 p) {
+    b.lo[0] = sel_lo(b.lo[0], p.x); b.lo[1] = sel_lo(b.lo[1], p.y); b.lo[2] = sel_lo(b.lo[2], p.z);
+    b.hi[0] = sel_hi(b.hi[0], p.x); b.hi[1] = sel_hi(b.hi[1], p.y); b.hi[2] = sel_hi(b.hi[2], p.z);
+    return b;
+}
+Aabb join(Aabb a, const Aabb &b) {
+    for (int k = 0; k < 3; k++) {
+        a.lo[k] = sel_lo(a.lo[k], b.lo[k]);
+        a.hi[k] = sel_hi(a.hi[k], b.hi[k]);
+    }
+    return a;
+}
+Aabb xf_box(const float *m, const Aabb &b) { // Bounds3 * Transform, transform.rs:645-657
+    Aabb r = rt::empty_box();
+    for (int c = 0; c < 8; c++)
+        r = grow(r, h_point(m, H3{(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1],
+                                  (c & 4) ? b.hi[2] : b.lo[2]}));
+    return r;
+}
+Aabb ball(const float c[3], float r) {
+    r = fabsf(r);
+    return Aabb{{c[0] - r, c[1] - r, c[2] - r}, {c[0] + r, c[1] + r, c[2] + r}};
+}
+
+template <class T>
+std::vector<T> copy_in(const T *p, size_t n) {
+    return p && n ? std::vector<T>(p, p + n) : std::vector<T>();
+}
+
+struct DeviceBuffers {
+    std::vector<void *> allocs;
+    rt::SceneDev dev{};
+    uint32_t grid = 0;
+    uint32_t *cursors = nullptr; // ring of work cursors for intersect / occluded launches
+    unsigned long long *counters = nullptr;
+    std::atomic<uint32_t> next_cursor{0};
+    uint64_t bytes = 0;
+    // render workspace (grown on demand)
+    std::mutex render_lock;
+    uint32_t ws_paths = 0, ws_depth = 0;
+    rt::Queue q[2]{};
+    float4 *radiance = nullptr;
+    uint32_t *counts = nullptr, *bounce_cursors = nullptr;
+    std::vector<void *> ws_allocs;
+};
+
+constexpr uint32_t kCursorRing = 1024;
+
+} // namespace
+
+struct rt_scene {
+    // host copies of what the description pointed to
+    std::vector<rt_prim_ref> prims;
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_moving_sphere> moving;
+    std::vector<float> tri_verts, tri_uvs, tri_normals;
+    std::vector<rt_rect> rects;
+    std::vector<rt_box> boxes;
+    std::vector<rt_gsphere> gspheres;
+    std::vector<rt::GSphere> gsph_derived;
+    std::vector<rt_xform> xforms;
+    std::vector<rt_medium> media;
+    std::vector<rt_material> materials;
+    std::vector<rt_texture> textures;
+    std::vector<std::vector<uint8_t>> image_data;
+    std::vector<rt_image> images;
+    std::vector<float> perlin_vec;
+    std::vector<int32_t> perlin_perm;
+    float background[3] = {0, 0, 0};
+    rt::BuiltTree tree;
+    double build_ms = 0;
+    std::mutex lock;
+    std::map<int, std::unique_ptr<DeviceBuffers>> devices;
+};
+
+namespace {
+
+rt::GSphere derive_gsphere(const rt_gsphere &in) { // Sphere::new, shapes/src/sphere.rs:28-47
+    rt::GSphere g{};
+    memcpy(g.o2w, in.o2w, sizeof g.o2w);
+    memcpy(g.w2o, in.w2o, sizeof g.w2o);
+    float r = in.radius;
+    float zlo = in.z_min < in.z_max ? in.z_min : in.z_max;
+    float zhi = in.z_min < in.z_max ? in.z_max : in.z_min;
+    g.radius = r;
+    g.z_min = rt::clampf(zlo, -r, r);
+    g.z_max = rt::clampf(zhi, -r, r);
+    g.theta_min = rt::p_acos(rt::clampf(g.z_min / r, -1.0f, 1.0f));
+    g.theta_max = rt::p_acos(rt::clampf(g.z_max / r, -1.0f, 1.0f));
+    g.phi_max = rt::clampf(in.phi_max_deg, 0.0f, 360.0f) * 0.0174532924f;
+    const float *m = in.o2w; // swaps_handedness, transform.rs:259-266
+    float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) +
+                m[2] * (m[4] * m[9] - m[5] * m[8]);
+    g.flip = det < 0.0f ? 1u : 0u;
+    return g;
+}
+
+bool validate(const rt_scene_desc *d) {
+    if (d->n_prims && !d->prims) return false;
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+        const rt_prim_ref &p = d->prims[i];
+        uint32_t kind = p.kind & 0xffu, lim = 0;
+        const void *table = nullptr;
+        switch (kind) {
+        case RT_SPHERE: lim = d->n_spheres; table = d->spheres; break;
+        case RT_MOVING_SPHERE: lim = d->n_moving_spheres; table = d->moving_spheres; break;
+        case RT_TRIANGLE: lim = d->n_tris; table = d->tri_verts; break;
+        case RT_RECT: lim = d->n_rects; table = d->rects; break;
+        case RT_BOX: lim = d->n_boxes; table = d->boxes; break;
+        case RT_GSPHERE: lim = d->n_gspheres; table = d->gspheres; break;
+        case RT_MEDIUM: lim = d->n_media; table = d->media; break;
+        default: return false;
+        }
+        if (p.index >= lim || !table) return false;
+        if (p.xform > d->n_xforms || p.xform > 0xffffu) return false;
+        if (d->n_materials && p.material >= d->n_materials) return false;
+        if (kind == RT_MEDIUM) {
+            const rt_medium &m = d->media[p.index];
+            if (m.boundary_kind == RT_BOUNDARY_SPHERE ? m.boundary_index >= d->n_spheres
+                                                      : m.boundary_index >= d->n_boxes)
+                return false;
+            if (m.xform > d->n_xforms) return false;
+        }
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->n_textures && d->materials[i].texture >= d->n_textures) return false;
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rt_texture &t = d->textures[i];
+        if ((t.kind == RT_TEX_CHECKER || t.kind == RT_TEX_CHECKER_UV) &&
+            (t.a >= d->n_textures || t.b >= d->n_textures))
+            return false;
+        if (t.kind == RT_TEX_IMAGE && t.a >= d->n_images) return false;
+        if (t.kind == RT_TEX_NOISE && (!d->perlin_vec || !d->perlin_perm)) return false;
+    }
+    return true;
+}
+
+Aabb prim_bounds(const rt_scene &s, const rt_prim_ref &pr) {
+    const uint32_t kind = pr.kind & 0xffu;
+    switch (kind) {
+    case RT_SPHERE: return ball(s.spheres[pr.index].c, s.spheres[pr.index].r);
+    case RT_MOVING_SPHERE: {
+        const rt_moving_sphere &m = s.moving[pr.index];
+        return join(ball(m.c0, m.r), ball(m.c1, m.r));
+    }
+    case RT_TRIANGLE: { // triangle.rs:100-106
+        const float *v = s.tri_verts.data() + 9 * (size_t)pr.index;
+        Aabb b = rt::empty_box();
+        for (int k = 0; k < 3; k++) b = grow(b, H3{v[3 * k], v[3 * k + 1], v[3 * k + 2]});
+        return b;
+    }
+    case RT_RECT: {
+        const rt_rect &r = s.rects[pr.index];
+        int A = r.axis == 0 ? 1 : 0, B = r.axis == 2 ? 1 : 2;
+        Aabb b;
+        b.lo[r.axis] = r.k - 1e-4f; b.hi[r.axis] = r.k + 1e-4f;
+        b.lo[A] = r.a0; b.hi[A] = r.a1;
+        b.lo[B] = r.b0; b.hi[B] = r.b1;
+        return pr.xform ? xf_box(s.xforms[pr.xform - 1].o2w, b) : b;
+    }
+    case RT_BOX: {
+        const rt_box &x = s.boxes[pr.index];
+        Aabb b{{x.lo[0], x.lo[1], x.lo[2]}, {x.hi[0], x.hi[1], x.hi[2]}};
+        return pr.xform ? xf_box(s.xforms[pr.xform - 1].o2w, b) : b;
+    }
+    case RT_GSPHERE: { // sphere.rs:59-64 through shapes/src/lib.rs:51-53
+        const rt::GSphere &g = s.gsph_derived[pr.index];
+        Aabb ob{{-g.radius, -g.radius, g.z_min}, {g.radius, g.radius, g.z_max}};
+        return xf_box(g.o2w, ob);
+    }
+    default: { // RT_MEDIUM
+        const rt_medium &m = s.media[pr.index];
+        if (m.boundary_kind == RT_BOUNDARY_SPHERE)
+            return ball(s.spheres[m.boundary_index].c, s.spheres[m.boundary_index].r);
+        const rt_box &x = s.boxes[m.boundary_index];
+        Aabb b{{x.lo[0], x.lo[1], x.lo[2]}, {x.hi[0], x.hi[1], x.hi[2]}};
+        return m.xform ? xf_box(s.xforms[m.xform - 1].o2w, b) : b;
+    }
+    }
+}
+
+template <class T>
+int upload(DeviceBuffers &db, const std::vector<T> &host, const T **dev) {
+    *dev = nullptr;
+    if (host.empty()) return RT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, host.size() * sizeof(T)));
+    db.allocs.push_back(p);
+    db.bytes += host.size() * sizeof(T);
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(p);
+    return RT_OK;
+}
+
+void release(DeviceBuffers &db) {
+    for (void *p : db.allocs) (void)hipFree(p);
+    for (void *p : db.ws_allocs) (void)hipFree(p);
+    db.allocs.clear();
+    db.ws_allocs.clear();
+}
+
+// Lays the scene out for the kernels: nodes as two float4 per node, the
+// primitive list in leaf order, and every typed table re-packed in the order
+// the leaves reference it so that a leaf's primitives sit next to each other.
+int build_device(rt_scene &s, int device, DeviceBuffers &db) {
+    HIP_TRY(hipSetDevice(device));
+    const auto &nodes = s.tree.nodes;
+    std::vector<float4> dn(2 * nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const rt_linear_node &n = nodes[i];
+        uint32_t meta = (uint32_t)n.primitive_count | ((uint32_t)n.axis << 16);
+        float w0, w1;
+        memcpy(&w0, &n.child_offset, 4);
+        memcpy(&w1, &meta, 4);
+        dn[2 * i] = make_float4(n.lo[0], n.lo[1], n.lo[2], w0);
+        dn[2 * i + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], w1);
+    }
+    std::vector<rt::LeafPrim> leaf(s.prims.size());
+    std::vector<float4> spheres, tris;
+    std::vector<float> uvs, normals;
+    std::vector<rt::MSphere> msph;
+    std::vector<rt_rect> rects;
+    std::vector<rt_box> boxes;
+    std::vector<rt::GSphere> gsph;
+    std::vector<rt::Medium> media;
+    auto push_sphere = [&](uint32_t idx) {
+        const rt_sphere &sp = s.spheres[idx];
+        spheres.push_back(make_float4(sp.c[0], sp.c[1], sp.c[2], sp.r));
+        return (uint32_t)spheres.size() - 1;
+    };
+    auto push_box = [&](uint32_t idx) {
+        boxes.push_back(s.boxes[idx]);
+        return (uint32_t)boxes.size() - 1;
+    };
+    for (size_t k = 0; k < leaf.size(); k++) {
+        const uint32_t id = s.tree.order[k];
+        const rt_prim_ref &pr = s.prims[id];
+        const uint32_t kind = pr.kind & 0xffu;
+        rt::LeafPrim lp{(pr.kind & 0x1ffu) | (pr.xform << 16), 0, id, pr.material};
+        switch (kind) {
+        case RT_SPHERE: lp.index = push_sphere(pr.index); break;
+        case RT_MOVING_SPHERE: {
+            const rt_moving_sphere &m = s.moving[pr.index];
+            rt::MSphere o{};
+            float dt = m.time1 - m.time0;
+            for (int c = 0; c < 3; c++) {
+                o.c0[c] = m.c0[c];
+                o.dcdt[c] = (m.c1[c] - m.c0[c]) / dt;
+            }
+            o.r = m.r;
+            o.time0 = m.time0;
+            msph.push_back(o);
+            lp.index = (uint32_t)msph.size() - 1;
+            break;
+        }
+        case RT_TRIANGLE: {
+            const float *v = s.tri_verts.data() + 9 * (size_t)pr.index;
+            for (int c = 0; c < 3; c++) tris.push_back(make_float4(v[3 * c], v[3 * c + 1], v[3 * c + 2], 0.0f));
+            if (!s.tri_uvs.empty())
+                uvs.insert(uvs.end(), s.tri_uvs.begin() + 6 * (size_t)pr.index,
+                           s.tri_uvs.begin() + 6 * (size_t)pr.index + 6);
+            if (!s.tri_normals.empty())
+                normals.insert(normals.end(), s.tri_normals.begin() + 9 * (size_t)pr.index,
+                               s.tri_normals.begin() + 9 * (size_t)pr.index + 9);
+            lp.index = (uint32_t)(tris.size() / 3) - 1;
+            break;
+        }
+        case RT_RECT:
+            rects.push_back(s.rects[pr.index]);
+            lp.index = (uint32_t)rects.size() - 1;
+            break;
+        case RT_BOX: lp.index = push_box(pr.index); break;
+        case RT_GSPHERE:
+            gsph.push_back(s.gsph_derived[pr.index]);
+            lp.index = (uint32_t)gsph.size() - 1;
+            break;
+        default: { // RT_MEDIUM
+            const rt_medium &m = s.media[pr.index];
+            rt::Medium o{m.boundary_kind, 0, m.xform, m.density};
+            o.boundary_index = m.boundary_kind == RT_BOUNDARY_SPHERE ? push_sphere(m.boundary_index)
+                                                                     : push_box(m.boundary_index);
+            media.push_back(o);
+            lp.index = (uint32_t)media.size() - 1;
+            break;
+        }
+        }
+        leaf[k] = lp;
+    }
+    rt::SceneDev &D = db.dev;
+    int rc;
+    if ((rc = upload(db, dn, &D.nodes))) return rc;
+    if ((rc = upload(db, leaf, &D.leaf))) return rc;
+    if ((rc = upload(db, spheres, &D.spheres))) return rc;
+    if ((rc = upload(db, msph, &D.msph))) return rc;
+    if ((rc = upload(db, tris, &D.tris))) return rc;
+    if ((rc = upload(db, uvs, &D.tri_uvs))) return rc;
+    if ((rc = upload(db, normals, &D.tri_normals))) return rc;
+    if ((rc = upload(db, rects, &D.rects))) return rc;
+    if ((rc = upload(db, boxes, &D.boxes))) return rc;
+    if ((rc = upload(db, gsph, &D.gsph))) return rc;
+    if ((rc = upload(db, s.xforms, &D.xforms))) return rc;
+    if ((rc = upload(db, media, &D.media))) return rc;
+    if ((rc = upload(db, s.materials, &D.materials))) return rc;
+    if ((rc = upload(db, s.textures, &D.textures))) return rc;
+    if ((rc = upload(db, s.perlin_vec, &D.perlin_vec))) return rc;
+    if ((rc = upload(db, s.perlin_perm, &D.perlin_perm))) return rc;
+    std::vector<rt::ImageDev> imgs;
+    for (size_t i = 0; i < s.images.size(); i++) {
+        const uint8_t *px = nullptr;
+        if ((rc = upload(db, s.image_data[i], &px))) return rc;
+        imgs.push_back(rt::ImageDev{px, s.images[i].w, s.images[i].h});
+    }
+    if ((rc = upload(db, imgs, &D.images))) return rc;
+    D.n_nodes = (uint32_t)nodes.size();
+    D.n_prims = (uint32_t)leaf.size();
+    memcpy(D.background, s.background, sizeof D.background);
+
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, kCursorRing * sizeof(uint32_t)));
+    db.allocs.push_back(p);
+    db.cursors = static_cast<uint32_t *>(p);
+    HIP_TRY(hipMalloc(&p, 16 * sizeof(unsigned long long)));
+    db.allocs.push_back(p);
+    db.counters = static_cast<unsigned long long *>(p);
+
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    // persistent grid: enough 256-thread blocks to fill every CU at the LDS-bound occupancy
+    uint32_t slots = s.tree.max_depth ? s.tree.max_depth : 1;
+    size_t lds = (size_t)slots * 256 * 4;
+    uint32_t per_cu = (uint32_t)(prop.maxSharedMemoryPerMultiProcessor / (lds ? lds : 1));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    db.grid = (uint32_t)prop.multiProcessorCount * per_cu;
+    return RT_OK;
+}
+
+int get_device(rt_scene *s, int device, DeviceBuffers **out) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device available; librt355 has no CPU path");
+    if (device < 0 || device >= count)
+        return fail(RT_ERR_NO_DEVICE, "device %d out of range (0..%d); librt355 has no CPU path", device,
+                    count - 1);
+    std::lock_guard<std::mutex> g(s->lock);
+    auto it = s->devices.find(device);
+    if (it == s->devices.end()) {
+        auto db = std::make_unique<DeviceBuffers>();
+        int rc = build_device(*s, device, *db);
+        if (rc != RT_OK) {
+            release(*db);
+            return rc;
+        }
+        it = s->devices.emplace(device, std::move(db)).first;
+    }
+    HIP_TRY(hipSetDevice(device));
+    *out = it->second.get();
+    return RT_OK;
+}
+
+uint32_t stack_slots(const rt_scene *s) { return s->tree.max_depth ? s->tree.max_depth : 1; }
+
+uint32_t *take_cursor(DeviceBuffers &db) { return db.cursors + (db.next_cursor++ % kCursorRing); }
+
+constexpr size_t kChunk = 1u << 28; // rays per launch (32-bit indices in the kernels)
+
+int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
+    if (paths <= db.ws_paths && depth <= db.ws_depth) return RT_OK;
+    for (void *p : db.ws_allocs) (void)hipFree(p);
+    db.ws_allocs.clear();
+    db.ws_paths = db.ws_depth = 0;
+    auto take = [&](size_t bytes, void **out) -> int {
+        HIP_TRY(hipMalloc(out, bytes));
+        db.ws_allocs.push_back(*out);
+        return RT_OK;
+    };
+    int rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.q[k].a))) return rc;
+        if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.q[k].b))) return rc;
+        if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.q[k].c))) return rc;
+        if ((rc = take((size_t)paths * sizeof(uint2), (void **)&db.q[k].d))) return rc;
+    }
+    if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.radiance))) return rc;
+    if ((rc = take((size_t)(depth + 2) * sizeof(uint32_t), (void **)&db.counts))) return rc;
+    if ((rc = take((size_t)(depth + 2) * sizeof(uint32_t), (void **)&db.bounce_cursors))) return rc;
+    db.ws_paths = paths;
+    db.ws_depth = depth;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error; }
+
+int rt_abi_sizes(uint32_t *out, size_t cap) {
+    const uint32_t sizes[] = {sizeof(rt_ray),        sizeof(rt_hit),         sizeof(rt_prim_ref),
+                              sizeof(rt_sphere),     sizeof(rt_moving_sphere), sizeof(rt_rect),
+                              sizeof(rt_box),        sizeof(rt_gsphere),     sizeof(rt_xform),
+                              sizeof(rt_medium),     sizeof(rt_material),    sizeof(rt_texture),
+                              sizeof(rt_image),      sizeof(rt_scene_desc),  sizeof(rt_build_opts),
+                              sizeof(rt_linear_node), sizeof(rt_scene_info), sizeof(rt_camera),
+                              sizeof(rt_render_opts), sizeof(rt_stats)};
+    size_t n = sizeof sizes / sizeof sizes[0];
+    if (n > cap) n = cap;
+    if (out) memcpy(out, sizes, n * sizeof(uint32_t));
+    return (int)n;
+}
+
+int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene **out) {
+    if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (!validate(d)) return fail(RT_ERR_INVALID, "malformed scene description");
+    try {
+        auto s = std::make_unique<rt_scene>();
+        s->prims = copy_in(d->prims, d->n_prims);
+        s->spheres = copy_in(d->spheres, d->n_spheres);
+        s->moving = copy_in(d->moving_spheres, d->n_moving_spheres);
+        s->tri_verts = copy_in(d->tri_verts, 9 * (size_t)d->n_tris);
+        s->tri_uvs = copy_in(d->tri_uvs, 6 * (size_t)d->n_tris);
+        s->tri_normals = copy_in(d->tri_normals, 9 * (size_t)d->n_tris);
+        s->rects = copy_in(d->rects, d->n_rects);
+        s->boxes = copy_in(d->boxes, d->n_boxes);
+        s->gspheres = copy_in(d->gspheres, d->n_gspheres);
+        s->xforms = copy_in(d->xforms, d->n_xforms);
+        s->media = copy_in(d->media, d->n_media);
+        s->materials = copy_in(d->materials, d->n_materials);
+        s->textures = copy_in(d->textures, d->n_textures);
+        s->perlin_vec = copy_in(d->perlin_vec, 768);
+        s->perlin_perm = copy_in(d->perlin_perm, 768);
+        for (uint32_t i = 0; i < d->n_images; i++) {
+            s->images.push_back(d->images[i]);
+            s->image_data.push_back(copy_in(d->images[i].rgb8, (size_t)d->images[i].w * d->images[i].h * 3));
+        }
+        memcpy(s->background, d->background, sizeof s->background);
+        for (const rt_gsphere &g : s->gspheres) s->gsph_derived.push_back(derive_gsphere(g));
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<Aabb> bounds(s->prims.size());
+        for (size_t i = 0; i < bounds.size(); i++) bounds[i] = prim_bounds(*s, s->prims[i]);
+        std::string err;
+        int rc = rt::build_tree(bounds, opts ? opts->max_prims_in_node : 4,
+                                opts ? opts->split_method : (uint32_t)RT_SPLIT_SAH, s->tree, err);
+        if (rc != RT_OK) return fail(rc, "%s", err.c_str());
+        s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *out = s.release();
+        return RT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_NOMEM, "out of host memory building the scene");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID, "scene construction failed: %s", e.what());
+    }
+}
+
+void rt_scene_destroy(rt_scene *s) {
+    if (!s) return;
+    for (auto &kv : s->devices) {
+        (void)hipSetDevice(kv.first);
+        release(*kv.second);
+    }
+    delete s;
+}
+
+int rt_scene_world_bound(const rt_scene *s, float out[6]) { // bvh.rs:728-734
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->tree.nodes.empty()) {
+        memcpy(out, s->tree.nodes[0].lo, 12);
+        memcpy(out + 3, s->tree.nodes[0].hi, 12);
+    } else {
+        Aabb e = rt::empty_box();
+        memcpy(out, e.lo, 12);
+        memcpy(out + 3, e.hi, 12);
+    }
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    out->n_prims = (uint32_t)s->prims.size();
+    out->n_nodes = (uint32_t)s->tree.nodes.size();
+    out->max_depth = s->tree.max_depth;
+    out->stack_slots = stack_slots(s);
+    for (auto &kv : s->devices) out->device_bytes = kv.second->bytes;
+    out->build_ms = s->build_ms;
+    return RT_OK;
+}
+
+int64_t rt_scene_get_nodes(const rt_scene *s, rt_linear_node *out, size_t cap) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    size_t n = std::min(cap, s->tree.nodes.size());
+    if (out && n) memcpy(out, s->tree.nodes.data(), n * sizeof *out);
+    return (int64_t)s->tree.nodes.size();
+}
+
+int64_t rt_scene_get_prim_order(const rt_scene *s, uint32_t *out, size_t cap) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    size_t n = std::min(cap, s->tree.order.size());
+    if (out && n) memcpy(out, s->tree.order.data(), n * sizeof *out);
+    return (int64_t)s->tree.order.size();
+}
+
+int rt_scene_upload(rt_scene *s, int device) {
+    DeviceBuffers *db;
+    return get_device(s, device, &db);
+}
+
+int rt_intersect_dev(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits, int device, void *stream) {
+    DeviceBuffers *db;
+    int rc = get_device(s, device, &db);
+    if (rc != RT_OK) return rc;
+    if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "null ray or hit buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t at = 0; at < n; at += kChunk) {
+        uint32_t m = (uint32_t)std::min(kChunk, n - at);
+        uint32_t *cur = take_cursor(*db);
+        HIP_TRY(hipMemsetAsync(cur, 0, sizeof(uint32_t), st));
+        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at, cur,
+                                     nullptr, st));
+    }
+    return RT_OK;
+}
+
+int rt_intersect_count(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits, int device,
+                       uint64_t out[9]) {
+    DeviceBuffers *db;
+    int rc = get_device(s, device, &db);
+    if (rc != RT_OK) return rc;
+    if (!out || (n && (!d_rays || !d_hits))) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(db->render_lock);
+    HIP_TRY(hipMemset(db->counters, 0, 16 * sizeof(unsigned long long)));
+    for (size_t at = 0; at < n; at += kChunk) {
+        uint32_t m = (uint32_t)std::min(kChunk, n - at);
+        uint32_t *cur = take_cursor(*db);
+        HIP_TRY(hipMemsetAsync(cur, 0, sizeof(uint32_t), nullptr));
+        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at, cur,
+                                     db->counters, nullptr));
+    }
+    HIP_TRY(hipMemcpy(out, db->counters, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_occluded_dev(rt_scene *s, const rt_ray *d_rays, size_t n, uint8_t *d_out, int device, void *stream) {
+    DeviceBuffers *db;
+    int rc = get_device(s, device, &db);
+    if (rc != RT_OK) return rc;
+    if (n && (!d_rays || !d_out)) return fail(RT_ERR_INVALID, "null ray or output buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (size_t at = 0; at < n; at += kChunk) {
+        uint32_t m = (uint32_t)std::min(kChunk, n - at);
+        uint32_t *cur = take_cursor(*db);
+        HIP_TRY(hipMemsetAsync(cur, 0, sizeof(uint32_t), st));
+        HIP_TRY(rt::launch_occluded(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_out + at, cur, st));
+    }
+    return RT_OK;
+}
+
+// host-pointer variants: stage through device memory in pieces
+static int staged(rt_scene *s, const rt_ray *rays, size_t n, rt_hit *hits, uint8_t *occ, int device) {
+    DeviceBuffers *db;
+    int rc = get_device(s, device, &db);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    if (!rays || (!hits && !occ)) return fail(RT_ERR_INVALID, "null ray or output buffer");
+    const size_t piece = std::min(n, (size_t)1 << 24);
+    rt_ray *d_rays = nullptr;
+    void *d_out = nullptr;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreate(&st));
+    hipError_t e1 = hipMalloc((void **)&d_rays, piece * sizeof(rt_ray));
+    hipError_t e2 = hipMalloc(&d_out, piece * (hits ? sizeof(rt_hit) : 1));
+    rc = RT_OK;
+    if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(RT_ERR_HIP, "hipMalloc of staging buffers failed");
+    for (size_t at = 0; at < n && rc == RT_OK; at += piece) {
+        size_t m = std::min(piece, n - at);
+        if (hipMemcpyAsync(d_rays, rays + at, m * sizeof(rt_ray), hipMemcpyHostToDevice, st) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "ray upload failed");
+            break;
+        }
+        rc = hits ? rt_intersect_dev(s, d_rays, m, static_cast<rt_hit *>(d_out), device, st)
+                  : rt_occluded_dev(s, d_rays, m, static_cast<uint8_t *>(d_out), device, st);
+        if (rc != RT_OK) break;
+        hipError_t e = hits ? hipMemcpyAsync(hits + at, d_out, m * sizeof(rt_hit), hipMemcpyDeviceToHost, st)
+                            : hipMemcpyAsync(occ + at, d_out, m, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(RT_ERR_HIP, "kernel or download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
+int rt_intersect(rt_scene *s, const rt_ray *rays, size_t n, rt_hit *hits, int device) {
+    if (n && !hits) return fail(RT_ERR_INVALID, "null hit buffer");
+    return staged(s, rays, n, hits, nullptr, device);
+}
+
+int rt_occluded(rt_scene *s, const rt_ray *rays, size_t n, uint8_t *out, int device) {
+    if (n && !out) return fail(RT_ERR_INVALID, "null output buffer");
+    return staged(s, rays, n, nullptr, out, device);
+}
+
+int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t first_path, size_t n,
+                     rt_ray *rays, int device) {
+    if (!cam || !opts || (n && !rays) || !opts->spp || !opts->width)
+        return fail(RT_ERR_INVALID, "bad argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(RT_ERR_NO_DEVICE, "device %d not available; librt355 has no CPU path", device);
+    if (n > kChunk) return fail(RT_ERR_LIMIT, "at most %zu rays per call", kChunk);
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    rt_ray *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, n * sizeof(rt_ray)));
+    hipError_t e = rt::launch_generate_rays(*cam, opts->width, opts->spp, opts->seed, first_path, (uint32_t)n,
+                                            d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(rays, d, n * sizeof(rt_ray), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "ray generation failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, float *d_rgba, rt_stats *stats,
+                  int device, void *stream) {
+    DeviceBuffers *db;
+    int rc = get_device(s, device, &db);
+    if (rc != RT_OK) return rc;
+    if (!cam || !o || !d_rgba) return fail(RT_ERR_INVALID, "null argument");
+    if (!o->width || !o->height || !o->spp || !o->max_depth) return fail(RT_ERR_INVALID, "empty frame");
+    if ((uint64_t)o->width * o->height * o->spp >= (1ull << 32))
+        return fail(RT_ERR_LIMIT, "width * height * spp must stay below 2^32");
+    if (s->materials.empty() && !s->prims.empty()) return fail(RT_ERR_INVALID, "scene has no materials");
+    const uint32_t shard_count = o->shard_count ? o->shard_count : 1;
+    if (o->shard_index >= shard_count) return fail(RT_ERR_INVALID, "shard index out of range");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> g(db->render_lock);
+
+    rt::FrameDev F{o->width, o->height, o->spp, (o->width + 31) / 32, o->shard_index, shard_count, o->seed};
+    const uint32_t tiles = F.tiles_x * ((o->height + 31) / 32);
+    const uint32_t my_tiles = tiles > o->shard_index ? (tiles - o->shard_index + shard_count - 1) / shard_count : 0;
+    const uint32_t n_ranks = my_tiles * 1024;
+    uint32_t max_paths = o->max_paths ? o->max_paths : (1u << 24);
+    if (max_paths < 1024) max_paths = 1024;
+    // samples per batch: as many as fit, all pixels of the shard in every batch
+    uint32_t s_batch = n_ranks ? max_paths / n_ranks : 1;
+    if (s_batch < 1) s_batch = 1;
+    if (s_batch > o->spp) s_batch = o->spp;
+    const uint64_t batch_paths64 = (uint64_t)n_ranks * s_batch;
+    if (batch_paths64 >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard too large for one sample per batch");
+    const uint32_t batch_paths = (uint32_t)batch_paths64;
+    if ((rc = grow_workspace(*db, batch_paths ? batch_paths : 1, o->max_depth)) != RT_OK) return rc;
+
+    const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
+    const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    HIP_TRY(hipEventCreate(&ev_begin));
+    HIP_TRY(hipEventCreate(&ev_end));
+    HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)o->width * o->height * 4 * sizeof(float), st));
+    if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(ev_begin, st));
+    uint64_t segments = 0, paths = 0, launches = 0;
+    uint32_t batches = 0, max_bounce = 0;
+    std::vector<uint32_t> counts(o->max_depth + 2);
+    for (uint32_t s0 = 0; s0 < o->spp && n_ranks; s0 += s_batch, batches++) {
+        const uint32_t sc = std::min(s_batch, o->spp - s0);
+        const uint32_t n_local = n_ranks * sc;
+        HIP_TRY(hipMemsetAsync(db->counts, 0, (o->max_depth + 2) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(db->bounce_cursors, 0, (o->max_depth + 2) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(db->radiance, 0, (size_t)n_local * sizeof(float4), st));
+        HIP_TRY(rt::launch_generate(F, *cam, db->q[0], &db->counts[0], n_local, s0, sc, st));
+        for (uint32_t b = 0; b < o->max_depth; b++) {
+            if (want_timing) {
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                HIP_TRY(hipEventRecord(e0, st));
+                ev.push_back(e0);
+                ev.push_back(e1);
+            }
+            HIP_TRY(rt::launch_bounce(db->dev, stack_slots(s), db->grid, db->q[b & 1], db->q[(b + 1) & 1],
+                                      db->counts, db->bounce_cursors, b, o->max_depth - 1, o->seed,
+                                      db->radiance, want_counters ? db->counters : nullptr, st));
+            if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
+            launches++;
+        }
+        HIP_TRY(rt::launch_resolve(F, db->radiance, n_ranks, sc, s0 + sc >= o->spp ? 1 : 0,
+                                   reinterpret_cast<float4 *>(d_rgba), st));
+        // queue sizes of this batch = ray segments traced per bounce
+        HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, (o->max_depth + 1) * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        paths += counts[0];
+        for (uint32_t b = 0; b < o->max_depth; b++) {
+            segments += counts[b];
+            if (counts[b] && b > max_bounce) max_bounce = b;
+        }
+    }
+    HIP_TRY(hipEventRecord(ev_end, st));
+    HIP_TRY(hipEventSynchronize(ev_end));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->paths = paths;
+        stats->segments = segments;
+        stats->trace_launches = launches;
+        stats->batches = batches;
+        stats->max_bounce = max_bounce;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        stats->total_ms = ms;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            stats->trace_ms += ms;
+        }
+        if (want_counters) {
+            unsigned long long c[9];
+            HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
+            stats->nodes_visited = c[0];
+            for (int k = 0; k < 8; k++) stats->prims_tested[k] = c[1 + k];
+        }
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ev_begin);
+    (void)hipEventDestroy(ev_end);
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, float *rgba, rt_stats *stats,
+              int device) {
+    DeviceBuffers *db;
+    int rc = get_device(s, device, &db);
+    if (rc != RT_OK) return rc;
+    if (!o || !rgba) return fail(RT_ERR_INVALID, "null argument");
+    const size_t bytes = (size_t)o->width * o->height * 4 * sizeof(float);
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, bytes ? bytes : 16));
+    rc = rt_render_dev(s, cam, o, d, stats, device, nullptr);
+    if (rc == RT_OK && hipMemcpy(rgba, d, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(RT_ERR_HIP, "framebuffer download failed");
+    (void)hipFree(d);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,572 @@
+// rt_kernels.hip -- gfx950 kernels: closest-hit / any-hit BVH traversal, camera
+// ray generation, the fused trace + shade + compact bounce kernel and the
+// framebuffer resolve.
+//
+// Execution shape: persistent workgroups of 256 threads (4 waves of 64).  Each
+// wave claims 64 rays at a time from a global cursor, so a launch is a fixed
+// grid of (CUs x resident blocks) however many rays are queued.  A lane's
+// traversal stack lives in LDS as stack[level * 256 + thread]: consecutive
+// lanes hit consecutive banks, so pushes and pops are conflict free.
+#include "rt_device.hpp"
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+constexpr int kBlock = 256;
+
+RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Claims `count` consecutive slots at *cursor for the whole wave with one atomic.
+RT_DEV uint32_t wave_claim(uint32_t *cursor, uint32_t count) {
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, count);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+struct Counters {
+    uint32_t nodes;
+    uint32_t prims[8];
+};
+
+// <BVH as Primitive>::intersect, shapes/src/bvh.rs:736-799, with the ray
+// shortened on every accepted hit (ties go to the primitive tested later).
+// Returns the leaf slot of the winning primitive or RT_MISS.
+template <bool ANY, bool COUNT>
+RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0, float &a1, float &a2,
+                         Counters *cnt) {
+    if (S.n_nodes == 0) return RT_MISS;
+    v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
+    bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
+    uint32_t sp = 0, cur = 0, best = RT_MISS;
+    for (;;) {
+        float4 n0 = S.nodes[2 * (size_t)cur];
+        float4 n1 = S.nodes[2 * (size_t)cur + 1];
+        if (COUNT) cnt->nodes++;
+        bool go_pop = true;
+        if (slab(n0, n1, ray, inv, negx, negy, negz)) {
+            uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
+            uint32_t count = meta & 0xffffu;
+            if (count > 0) { // leaf, bvh.rs:763-776
+                for (uint32_t i = 0; i < count; i++) {
+                    LeafPrim lp = S.leaf[off + i];
+                    float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                    if (COUNT) cnt->prims[lp.kind & 7u]++;
+                    if (prim_test(S, lp, ray, t, b0, b1, b2)) {
+                        if (ANY) return off + i;
+                        ray.t_max = t;
+                        best = off + i;
+                        a0 = b0; a1 = b1; a2 = b2;
+                    }
+                }
+            } else { // interior, bvh.rs:778-787
+                uint32_t axis = meta >> 16;
+                bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                uint32_t far_child = neg ? cur + 1 : off;
+                cur = neg ? off : cur + 1;
+                stack[sp * kBlock] = far_child;
+                sp++;
+                go_pop = false;
+            }
+        }
+        if (go_pop) {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * kBlock];
+        }
+    }
+    return best;
+}
+
+RT_DEV Ray load_ray(const rt_ray *rays, size_t i) {
+    const float4 *p = reinterpret_cast<const float4 *>(rays + i);
+    float4 a = p[0], b = p[1];
+    Ray r;
+    r.o = mk(a.x, a.y, a.z);
+    r.d = mk(a.w, b.x, b.y);
+    r.t_max = b.z;
+    r.time = b.w;
+    return r;
+}
+
+RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
+    // wave reduction, then one atomic per wave and counter
+    uint32_t v[9] = {c.nodes, c.prims[0], c.prims[1], c.prims[2], c.prims[3], c.prims[4], c.prims[5],
+                     c.prims[6], c.prims[7]};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint32_t x = v[k];
+        for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[k], (unsigned long long)x);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(SceneDev S, const rt_ray *rays, uint32_t n,
+                                                      rt_hit *hits, uint32_t *cursor,
+                                                      unsigned long long *counters) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    Counters cnt = {};
+    for (;;) {
+        uint32_t base = wave_claim(cursor, 64);
+        if (base >= n) break;
+        uint32_t i = base + lane;
+        if (i < n) {
+            Ray ray = load_ray(rays, i);
+            const Ray ray0 = ray;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, &cnt);
+            float4 h0, h1;
+            if (slot != RT_MISS) {
+                LeafPrim lp = S.leaf[slot];
+                Surf sf;
+                prim_finalize(S, lp, ray0, ray.t_max, a0, a1, a2, sf);
+                h0 = make_float4(sf.t, __uint_as_float(lp.prim), sf.u, sf.v);
+                h1 = make_float4(sf.n.x, sf.n.y, sf.n.z, __uint_as_float(sf.flags));
+            } else {
+                h0 = make_float4(kInf, __uint_as_float(RT_MISS), 0.0f, 0.0f);
+                h1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            float4 *o = reinterpret_cast<float4 *>(hits + i);
+            o[0] = h0;
+            o[1] = h1;
+        }
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
+__global__ __launch_bounds__(kBlock) void k_occluded(SceneDev S, const rt_ray *rays, uint32_t n,
+                                                     uint8_t *out, uint32_t *cursor) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t base = wave_claim(cursor, 64);
+        if (base >= n) break;
+        uint32_t i = base + lane;
+        if (i < n) {
+            Ray ray = load_ray(rays, i);
+            float a0, a1, a2;
+            uint32_t slot = traverse<true, false>(S, ray, stack, a0, a1, a2, nullptr);
+            out[i] = slot != RT_MISS ? 1 : 0;
+        }
+    }
+}
+
+// ---- camera, colour/src/camera/perspective.rs:54-78 -----------------------------------------
+RT_DEV void concentric_disk(float u, float v, float &dx, float &dy) { // sampling.rs:4-22
+    float ox = u * 2.0f - 1.0f, oy = v * 2.0f - 1.0f;
+    if (ox == 0.0f && oy == 0.0f) { dx = 0.0f; dy = 0.0f; return; }
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) {
+        r = ox;
+        theta = 0.785398163f * (oy / ox);
+    } else {
+        r = oy;
+        theta = 1.57079637f - 0.785398163f * (ox / oy);
+    }
+    dx = p_cos(theta) * r;
+    dy = p_sin(theta) * r;
+}
+
+RT_DEV Ray camera_ray(const rt_camera &cam, float fx, float fy, float lu, float lv, float tu) {
+    const float *m = cam.raster_to_camera;
+    float xp = m[0] * fx + m[1] * fy + m[2] * 0.0f + m[3];
+    float yp = m[4] * fx + m[5] * fy + m[6] * 0.0f + m[7];
+    float zp = m[8] * fx + m[9] * fy + m[10] * 0.0f + m[11];
+    float wp = m[12] * fx + m[13] * fy + m[14] * 0.0f + m[15];
+    v3 pc = mk(xp, yp, zp);
+    if (wp != 1.0f) pc = pc / wp;
+    v3 o = mk(0.0f, 0.0f, 0.0f);
+    v3 d = normalize(pc);
+    if (cam.lens_radius > 0.0f) {
+        float lx, ly;
+        concentric_disk(lu, lv, lx, ly);
+        lx *= cam.lens_radius;
+        ly *= cam.lens_radius;
+        float ft = cam.focal_distance / d.z;
+        v3 focus = d * ft;
+        o = mk(lx, ly, 0.0f);
+        d = normalize(focus - o);
+    }
+    float time = (1.0f - tu) * cam.shutter_open + tu * cam.shutter_close;
+    const float *c = cam.camera_to_world; // ray * transform, transform.rs:530-552
+    v3 wo = xf_point(c, o);
+    v3 oerr = xf_abs_sum(c, o) * G3;
+    v3 wd = xf_vector(c, d);
+    float len_sq = dot(wd, wd);
+    float t_max = kInf;
+    if (len_sq > 0.0f) {
+        float dt = dot(vabs(wd), oerr) / len_sq;
+        wo = wo + wd * dt;
+        t_max -= dt;
+    }
+    Ray r;
+    r.o = wo;
+    r.d = wd;
+    r.t_max = t_max;
+    r.time = time;
+    return r;
+}
+
+// path = pixel * spp + sample; PCG32 sequence = seed * 2^32 + path; draws: film x, film y,
+// time, lens u, lens v
+RT_DEV Ray path_setup(const rt_camera &cam, uint32_t width, uint32_t spp, uint64_t seed, uint64_t path,
+                      Rng &rng) {
+    uint64_t pixel = path / spp;
+    uint32_t px = (uint32_t)(pixel % width), py = (uint32_t)(pixel / width);
+    rng_seq(rng, (seed << 32) + path);
+    float u1 = rng_f(rng), u2 = rng_f(rng), ut = rng_f(rng);
+    float l1 = rng_f(rng), l2 = rng_f(rng);
+    return camera_ray(cam, (float)px + u1, (float)py + u2, l1, l2, ut);
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate_rays(rt_camera cam, uint32_t width, uint32_t spp,
+                                                          uint64_t seed, uint64_t first, uint32_t n,
+                                                          rt_ray *rays) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Rng rng;
+    Ray r = path_setup(cam, width, spp, seed, first + i, rng);
+    float4 *o = reinterpret_cast<float4 *>(rays + i);
+    o[0] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+    o[1] = make_float4(r.d.y, r.d.z, r.t_max, r.time);
+}
+
+// ---- bounce queues ------------------------------------------------------------------------------
+RT_DEV void queue_push(const Queue &q, uint32_t slot, const Ray &r, uint32_t local, v3 beta,
+                       const Rng &rng, uint32_t gpath) {
+    q.a[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
+    q.b[slot] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(local));
+    q.c[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
+    q.d[slot] = make_uint2((uint32_t)(rng.state >> 32), gpath);
+}
+
+// Appends the lanes with `alive` set to the queue: ballot, rank by prefix count,
+// one atomic per wave for the tail (stream compaction).
+RT_DEV uint32_t compact_slot(bool alive, uint32_t *tail) {
+    uint64_t mask = __ballot(alive);
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (total) base = wave_claim(tail, total);
+    return base + lane_rank(mask);
+}
+
+// pixel owned by this shard with rank r: 32x32 tiles, tile t = shard_index + k * shard_count
+RT_DEV bool rank_to_pixel(const FrameDev &F, uint32_t rank, uint32_t &px, uint32_t &py) {
+    uint32_t tile = F.shard_index + (rank >> 10) * F.shard_count;
+    uint32_t within = rank & 1023u;
+    uint32_t tx = tile % F.tiles_x, ty = tile / F.tiles_x;
+    px = tx * 32 + (within & 31u);
+    py = ty * 32 + (within >> 5);
+    return px < F.width && py < F.height;
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, Queue q, uint32_t *tail,
+                                                     uint32_t n_local, uint32_t s0, uint32_t s_count) {
+    uint32_t local = blockIdx.x * kBlock + threadIdx.x;
+    bool alive = false;
+    Ray ray;
+    Rng rng;
+    uint32_t gpath = 0;
+    if (local < n_local) {
+        uint32_t rank = local / s_count, s = s0 + local % s_count, px, py;
+        if (rank_to_pixel(F, rank, px, py)) {
+            gpath = (py * F.width + px) * F.spp + s;
+            ray = path_setup(cam, F.width, F.spp, F.seed, gpath, rng);
+            alive = true;
+        }
+    }
+    uint32_t slot = compact_slot(alive, tail);
+    if (alive) queue_push(q, slot, ray, local, mk(1.0f, 1.0f, 1.0f), rng, gpath);
+}
+
+// ---- textures -----------------------------------------------------------------------------------
+RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = u * u * (3.0f - 2.0f * u);
+    float vv = v * v * (3.0f - 2.0f * v);
+    float ww = w * w * (3.0f - 2.0f * w);
+    const int32_t *px = S.perlin_perm, *py = S.perlin_perm + 256, *pz = S.perlin_perm + 512;
+    float accum = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255];
+                const float *c = S.perlin_vec + 3 * idx;
+                float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+                float dt = c[0] * wx + c[1] * wy + c[2] * wz;
+                float fi = di ? uu : 1.0f - uu;
+                float fj = dj ? vv : 1.0f - vv;
+                float fk = dk ? ww : 1.0f - ww;
+                accum += fi * fj * fk * dt;
+            }
+    return accum;
+}
+RT_DEV float perlin_turb(const SceneDev &S, v3 p) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * perlin_noise(S, p);
+        weight *= 0.5f;
+        p = p * 2.0f;
+    }
+    return fabsf(accum);
+}
+
+RT_DEV v3 texture_value(const SceneDev &S, uint32_t tex, float u, float v, v3 p) {
+    for (int level = 0; level < 8; level++) {
+        rt_texture t = S.textures[tex];
+        switch (t.kind) {
+        case RT_TEX_CHECKER: {
+            float sines = p_sin(t.scale * p.x) * p_sin(t.scale * p.y) * p_sin(t.scale * p.z);
+            tex = sines < 0.0f ? t.a : t.b;
+            continue;
+        }
+        case RT_TEX_CHECKER_UV: {
+            int cu = (int)floorf(u * t.scale), cv = (int)floorf(v * t.scale);
+            tex = ((cu + cv) & 1) ? t.a : t.b;
+            continue;
+        }
+        case RT_TEX_IMAGE: {
+            ImageDev im = S.images[t.a];
+            float uc = clampf(u, 0.0f, 1.0f), vc = 1.0f - clampf(v, 0.0f, 1.0f);
+            int i = (int)(uc * (float)im.w), j = (int)(vc * (float)im.h);
+            if (i >= (int)im.w) i = (int)im.w - 1;
+            if (j >= (int)im.h) j = (int)im.h - 1;
+            const uint8_t *px = im.rgb8 + 3 * ((size_t)j * im.w + (size_t)i);
+            const float sc = 1.0f / 255.0f;
+            return mk((float)px[0] * sc, (float)px[1] * sc, (float)px[2] * sc);
+        }
+        case RT_TEX_NOISE: {
+            float g = 0.5f * (1.0f + p_sin(t.scale * p.z + 10.0f * perlin_turb(S, p)));
+            return mk(g, g, g);
+        }
+        default: return mk(t.rgb[0], t.rgb[1], t.rgb[2]);
+        }
+    }
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+RT_DEV v3 random_in_unit_sphere(Rng &rng) {
+    for (;;) {
+        float x = 2.0f * rng_f(rng) - 1.0f;
+        float y = 2.0f * rng_f(rng) - 1.0f;
+        float z = 2.0f * rng_f(rng) - 1.0f;
+        if (x * x + y * y + z * z < 1.0f) return mk(x, y, z);
+    }
+}
+RT_DEV v3 reflect(v3 v, v3 n) { return v - n * (2.0f * dot(v, n)); }
+
+// spawn_ray origin, shapes/src/interaction.rs:86-99 + geometry/src/lib.rs:129-151
+RT_DEV v3 offset_origin(v3 p, v3 err, v3 n, v3 w) {
+    float d = dot(vabs(n), err);
+    v3 off = n * d;
+    if (dot(n, w) < 0.0f) off = -off;
+    v3 po = p + off;
+    if (off.x > 0.0f) po.x = next_float_up(po.x); else if (off.x < 0.0f) po.x = next_float_down(po.x);
+    if (off.y > 0.0f) po.y = next_float_up(po.y); else if (off.y < 0.0f) po.y = next_float_down(po.y);
+    if (off.z > 0.0f) po.z = next_float_up(po.z); else if (off.z < 0.0f) po.z = next_float_down(po.z);
+    return po;
+}
+
+// One bounce of every queued path: closest hit, shading, scatter, and the
+// survivors compacted into the next queue.  Radiance is stored once, when a
+// path ends on a light or leaves the scene.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue qout, uint32_t *counts,
+                                                   uint32_t *cursors, uint32_t bounce, uint32_t last,
+                                                   uint64_t seed, float4 *radiance,
+                                                   unsigned long long *counters) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = counts[bounce];
+    Counters cnt = {};
+    for (;;) {
+        uint32_t base = wave_claim(&cursors[bounce], 64);
+        if (base >= n) break;
+        uint32_t i = base + lane;
+        bool alive = false;
+        Ray ray;
+        Rng rng;
+        v3 beta = mk(0.0f, 0.0f, 0.0f);
+        uint32_t local = 0, gpath = 0;
+        if (i < n) {
+            float4 qa = qin.a[i], qb = qin.b[i], qc = qin.c[i];
+            uint2 qd = qin.d[i];
+            ray.o = mk(qa.x, qa.y, qa.z);
+            ray.time = qa.w;
+            ray.d = mk(qb.x, qb.y, qb.z);
+            ray.t_max = kInf;
+            local = __float_as_uint(qb.w);
+            beta = mk(qc.x, qc.y, qc.z);
+            gpath = qd.y;
+            rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
+            rng.inc = (((seed << 32) + gpath) << 1) | 1u;
+            alive = true;
+        }
+        if (alive) {
+            const Ray ray0 = ray;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, &cnt);
+            if (slot == RT_MISS) {
+                radiance[local] = make_float4(beta.x * S.background[0], beta.y * S.background[1],
+                                              beta.z * S.background[2], 0.0f);
+                alive = false;
+            } else {
+                LeafPrim lp = S.leaf[slot];
+                Surf h;
+                prim_finalize(S, lp, ray0, ray.t_max, a0, a1, a2, h);
+                v3 d = ray0.d;
+                bool front = dot(d, h.n) < 0.0f;
+                v3 nf = front ? h.n : -h.n;
+                rt_material m = S.materials[lp.material];
+                v3 dir = nf;
+                if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
+                    v3 e = texture_value(S, m.texture, h.u, h.v, h.p);
+                    radiance[local] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
+                    alive = false;
+                } else if (m.kind == RT_MAT_LAMBERTIAN) {
+                    v3 r = random_in_unit_sphere(rng);
+                    dir = nf + r;
+                    if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = nf;
+                    dir = normalize(dir);
+                    v3 a = texture_value(S, m.texture, h.u, h.v, h.p);
+                    beta = mk(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+                } else if (m.kind == RT_MAT_METALLIC) {
+                    v3 r = random_in_unit_sphere(rng);
+                    dir = reflect(d, nf) + r * m.fuzz;
+                    if (!(dot(dir, nf) > 0.0f)) {
+                        alive = false; // absorbed
+                    } else {
+                        dir = normalize(dir);
+                        v3 a = texture_value(S, m.texture, h.u, h.v, h.p);
+                        beta = mk(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+                    }
+                } else if (m.kind == RT_MAT_DIELECTRIC) {
+                    float ratio = front ? 1.0f / m.ior : m.ior;
+                    float cos_t = sel_min(dot(-d, nf), 1.0f);
+                    float sin_t = sqrtf(1.0f - cos_t * cos_t);
+                    bool reflect_it = ratio * sin_t > 1.0f;
+                    if (!reflect_it) {
+                        float r0 = (1.0f - ratio) / (1.0f + ratio);
+                        r0 = r0 * r0;
+                        float c = 1.0f - cos_t;
+                        float refl = r0 + (1.0f - r0) * (c * c * c * c * c);
+                        reflect_it = refl > rng_f(rng);
+                    }
+                    if (reflect_it) {
+                        dir = reflect(d, nf);
+                    } else {
+                        v3 perp = (d + nf * cos_t) * ratio;
+                        float k = 1.0f - dot(perp, perp);
+                        v3 par = nf * -sqrtf(fabsf(k));
+                        dir = perp + par;
+                    }
+                    dir = normalize(dir);
+                } else { // RT_MAT_ISOTROPIC
+                    dir = normalize(random_in_unit_sphere(rng));
+                    v3 a = texture_value(S, m.texture, h.u, h.v, h.p);
+                    beta = mk(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+                }
+                if (alive) {
+                    ray.o = offset_origin(h.p, h.perr, h.n, dir);
+                    ray.d = dir;
+                    ray.t_max = kInf;
+                }
+            }
+            if (bounce == last) alive = false; // depth exhausted: the path contributes nothing
+        }
+        uint32_t slot = compact_slot(alive, &counts[bounce + 1]);
+        if (alive) queue_push(qout, slot, ray, local, beta, rng, gpath);
+    }
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// Adds the batch's samples to the running per-pixel sums in sample order; the
+// last batch divides by spp.  One thread per owned pixel.
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameDev F, const float4 *radiance, uint32_t n_ranks,
+                                                    uint32_t s_count, int finish, float4 *rgba) {
+    uint32_t rank = blockIdx.x * kBlock + threadIdx.x, px, py;
+    if (rank >= n_ranks || !rank_to_pixel(F, rank, px, py)) return;
+    size_t pix = (size_t)py * F.width + px;
+    float4 acc = rgba[pix];
+    const float4 *r = radiance + (size_t)rank * s_count;
+    for (uint32_t s = 0; s < s_count; s++) {
+        float4 v = r[s];
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+    }
+    if (finish) {
+        float inv = (float)F.spp;
+        acc.x = acc.x / inv;
+        acc.y = acc.y / inv;
+        acc.z = acc.z / inv;
+        acc.w = 1.0f;
+    }
+    rgba[pix] = acc;
+}
+
+// ---- host-side launchers ------------------------------------------------------------------------------
+static inline size_t stack_bytes(uint32_t slots) { return (size_t)slots * kBlock * sizeof(uint32_t); }
+
+hipError_t launch_intersect(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
+                            rt_hit *hits, uint32_t *cursor, unsigned long long *counters,
+                            hipStream_t stream) {
+    if (counters)
+        hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, rays,
+                           n, hits, cursor, counters);
+    else
+        hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, rays,
+                           n, hits, cursor, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_occluded(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
+                           uint8_t *out, uint32_t *cursor, hipStream_t stream) {
+    hipLaunchKernelGGL(k_occluded, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, rays, n, out,
+                       cursor);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_rays(const rt_camera &cam, uint32_t width, uint32_t spp, uint64_t seed,
+                                uint64_t first, uint32_t n, rt_ray *rays, hipStream_t stream) {
+    hipLaunchKernelGGL(k_generate_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, width,
+                       spp, seed, first, n, rays);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *tail,
+                           uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream) {
+    hipLaunchKernelGGL(k_generate, dim3((n_local + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, cam, q,
+                       tail, n_local, s0, s_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_bounce(const SceneDev &S, uint32_t slots, uint32_t grid, const Queue &qin, const Queue &qout,
+                         uint32_t *counts, uint32_t *cursors, uint32_t bounce, uint32_t last, uint64_t seed,
+                         float4 *radiance, unsigned long long *counters, hipStream_t stream) {
+    if (counters)
+        hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, qin, qout,
+                           counts, cursors, bounce, last, seed, radiance, counters);
+    else
+        hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, qin, qout,
+                           counts, cursors, bounce, last, seed, radiance, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const FrameDev &F, const float4 *radiance, uint32_t n_ranks, uint32_t s_count,
+                          int finish, float4 *rgba, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3((n_ranks + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, radiance,
+                       n_ranks, s_count, finish, rgba);
+    return hipGetLastError();
+}
+
+} // namespace rt

@@ -1,0 +1,154 @@
+"""ctypes wrapper around the CPU oracle (oracle/liborc.so).
+
+Test infrastructure: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import abi
+
+ORACLE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "liborc.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liborc.so"])
+        L = C.CDLL(path)
+        abi.declare(L, prefix="orc_")
+        vp, sz, i32, u64, P = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER
+        L.orc_scene_set_tree.restype = i32
+        L.orc_scene_set_tree.argtypes = [vp, vp, sz, vp, sz]
+        L.orc_intersect.restype = i32
+        L.orc_intersect.argtypes = [vp, vp, sz, vp, i32, vp]
+        L.orc_occluded.restype = i32
+        L.orc_occluded.argtypes = [vp, vp, sz, vp, i32]
+        L.orc_intersect_brute.restype = i32
+        L.orc_intersect_brute.argtypes = [vp, vp, sz, vp, i32]
+        L.orc_generate_rays.restype = i32
+        L.orc_generate_rays.argtypes = [P(abi.rt_camera), P(abi.rt_render_opts), u64, sz, vp]
+        L.orc_render.restype = i32
+        L.orc_render.argtypes = [vp, P(abi.rt_camera), P(abi.rt_render_opts), vp, P(abi.rt_stats), i32]
+        L.orc_path_radiance.restype = i32
+        L.orc_path_radiance.argtypes = [vp, P(abi.rt_camera), P(abi.rt_render_opts), u64, sz, vp, vp]
+        L.orc_bounds_union.argtypes = [vp, vp, vp]
+        L.orc_bounds_distance_squared.restype = C.c_float
+        L.orc_bounds_distance_squared.argtypes = [vp, vp]
+        L.orc_bounds_surface_area.restype = C.c_float
+        L.orc_bounds_surface_area.argtypes = [vp]
+        L.orc_slab_test.restype = i32
+        L.orc_slab_test.argtypes = [vp, vp]
+        L.orc_pcg32_stream.argtypes = [u64, vp, sz]
+        L.orc_pcg32_floats.argtypes = [u64, vp, sz]
+        L.orc_math_eval.restype = C.c_float
+        L.orc_math_eval.argtypes = [i32, C.c_float, C.c_float]
+        L.orc_offset_ray_origin.argtypes = [vp, vp, vp, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError("oracle error %d: %s" % (rc, lib().orc_last_error().decode()))
+
+
+def make_opts(max_prims=4, split=abi.RT_SPLIT_SAH):
+    return abi.rt_build_opts(max_prims, split)
+
+
+def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0):
+    return abi.rt_render_opts(width, height, spp, max_depth, seed, shard[0], shard[1], max_paths,
+                              flags)
+
+
+class OracleScene:
+    def __init__(self, frozen, max_prims=4, split=abi.RT_SPLIT_SAH):
+        self.frozen = frozen
+        h = C.c_void_p()
+        opts = make_opts(max_prims, split)
+        _check(lib().orc_scene_create(C.byref(frozen.desc), C.byref(opts), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def info(self):
+        i = abi.rt_scene_info()
+        _check(lib().orc_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def world_bound(self):
+        out = (C.c_float * 6)()
+        _check(lib().orc_scene_world_bound(self.h, C.byref(out)))
+        return np.array(out[:], dtype=np.float32)
+
+    def nodes(self):
+        n = lib().orc_scene_get_nodes(self.h, None, 0)
+        out = np.zeros(n, dtype=abi.linear_node_dtype)
+        lib().orc_scene_get_nodes(self.h, out.ctypes.data, n)
+        return out
+
+    def prim_order(self):
+        n = lib().orc_scene_get_prim_order(self.h, None, 0)
+        out = np.zeros(n, dtype=np.uint32)
+        lib().orc_scene_get_prim_order(self.h, out.ctypes.data, n)
+        return out
+
+    def set_tree(self, nodes, order):
+        nodes = np.ascontiguousarray(nodes, dtype=abi.linear_node_dtype)
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        _check(lib().orc_scene_set_tree(self.h, nodes.ctypes.data, len(nodes), order.ctypes.data,
+                                        len(order)))
+
+    def intersect(self, rays, threads=8, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+        hits = np.zeros(len(rays), dtype=abi.hit_dtype)
+        cnt = np.zeros(9, dtype=np.uint64)
+        _check(lib().orc_intersect(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, threads,
+                                   cnt.ctypes.data if counters else None))
+        return (hits, cnt) if counters else hits
+
+    def intersect_brute(self, rays, threads=8):
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+        hits = np.zeros(len(rays), dtype=abi.hit_dtype)
+        _check(lib().orc_intersect_brute(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, threads))
+        return hits
+
+    def occluded(self, rays, threads=8):
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+        out = np.zeros(len(rays), dtype=np.uint8)
+        _check(lib().orc_occluded(self.h, rays.ctypes.data, len(rays), out.ctypes.data, threads))
+        return out
+
+    def render(self, cam, opts, threads=8):
+        img = np.zeros((opts.height, opts.width, 4), dtype=np.float32)
+        st = abi.rt_stats()
+        _check(lib().orc_render(self.h, C.byref(cam), C.byref(opts), img.ctypes.data, C.byref(st),
+                                threads))
+        return img, st
+
+    def path_radiance(self, cam, opts, first, n):
+        rgb = np.zeros((n, 3), dtype=np.float32)
+        seg = np.zeros(n, dtype=np.uint32)
+        _check(lib().orc_path_radiance(self.h, C.byref(cam), C.byref(opts), first, n,
+                                       rgb.ctypes.data, seg.ctypes.data))
+        return rgb, seg
+
+
+def generate_rays(cam, opts, first, n):
+    rays = np.zeros(n, dtype=abi.ray_dtype)
+    _check(lib().orc_generate_rays(C.byref(cam), C.byref(opts), first, n, rays.ctypes.data))
+    return rays
