@@ -25,6 +25,15 @@ class RtError(RuntimeError):
 def load():
     global _LIB
     if _LIB is None:
+        if os.environ.get("RT355_NO_TORCH") != "1":
+            # PyTorch bundles its own HIP runtime under the same SONAME as the
+            # system one.  Loading it first makes the dynamic loader hand that
+            # single copy to librt355 too; two runtimes in one process cannot
+            # both open the GPU.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s not found: build it with `python -m raytracer_amd.build` "

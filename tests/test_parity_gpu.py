@@ -1,0 +1,202 @@
+"""GPU parity: every result of the HIP path (through the C ABI) is compared with
+the CPU oracle on identical inputs.  Hit/miss, primitive index, t, (u,v), the
+normal and the face flags must be bit-identical; radiance of individual paths
+and whole images must be bit-identical too, because both sides evaluate the
+same fp32 expressions in the same order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, lib
+from tests import orc
+from tests.conftest import random_rays
+from tests.mixed import mixed_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_hits_equal(a, b, what=""):
+    for f in ("prim", "flags"):
+        bad = np.nonzero(a[f] != b[f])[0]
+        assert len(bad) == 0, "%s: %s differs at %d rays, first %s" % (what, f, len(bad), bad[:5])
+    for f in ("t", "u", "v", "n"):
+        x, y = a[f].view(np.uint32), b[f].view(np.uint32)
+        bad = np.nonzero((x != y).reshape(len(a), -1).any(axis=1))[0]
+        assert len(bad) == 0, "%s: %s differs at %d rays, first %s: %s vs %s" % (
+            what, f, len(bad), bad[:5], a[f][bad[:3]], b[f][bad[:3]])
+
+
+def scene_rays(o, cam, n_cam=1 << 15, n_rand=1 << 15, seed=3):
+    wb = o.world_bound()
+    lo, hi = np.maximum(wb[:3], -2000), np.minimum(wb[3:], 2000)
+    opts = orc.render_opts(256, 128, 1)
+    prim = orc.generate_rays(cam(256, 128), opts, 0, min(n_cam, 256 * 128))
+    return np.concatenate([prim, random_rays(n_rand, lo, hi, seed)])
+
+
+@pytest.mark.parametrize("name", ["random", "cornell", "week", "pbrt"])
+@pytest.mark.parametrize("split", [abi.RT_SPLIT_SAH, abi.RT_SPLIT_HLBVH])
+def test_intersect_named_scenes(scene_cache, name, split):
+    sd, cam, fr = scene_cache(name)
+    o = orc.OracleScene(fr, 4, split)
+    g = lib.Scene(fr, 4, split)
+    assert g.nodes().tobytes() == o.nodes().tobytes()
+    rays = scene_rays(o, cam)
+    ref = o.intersect(rays)
+    got = g.intersect(rays)
+    assert (ref["prim"] != abi.RT_MISS).mean() > 0.2
+    assert_hits_equal(got, ref, name)
+    occ = g.does_intersect(rays)
+    assert (occ == o.occluded(rays)).all()
+    assert ((ref["prim"] != abi.RT_MISS) == (occ != 0)).all()
+
+
+@pytest.mark.parametrize("split", range(4))
+@pytest.mark.parametrize("max_prims", [1, 4, 32])
+def test_intersect_mixed_scene_all_builders(split, max_prims):
+    fr = mixed_scene(seed=5 + split, n_each=60).freeze()
+    o = orc.OracleScene(fr, max_prims, split)
+    g = lib.Scene(fr, max_prims, split)
+    assert g.nodes().tobytes() == o.nodes().tobytes()
+    assert (g.prim_order() == o.prim_order()).all()
+    wb = o.world_bound()
+    rays = random_rays(1 << 16, np.maximum(wb[:3], -30), np.minimum(wb[3:], 30), 11 + split)
+    ref = o.intersect(rays)
+    kinds = set(np.unique(ref["flags"][ref["prim"] != abi.RT_MISS] & 0xFF))
+    assert kinds == set(range(7)), kinds  # every primitive kind is hit by some ray
+    assert_hits_equal(g.intersect(rays), ref, "mixed")
+    assert (g.does_intersect(rays) == o.occluded(rays)).all()
+
+
+def test_counters_match_oracle(scene_cache):
+    import torch
+    sd, cam, fr = scene_cache("week")
+    o = orc.OracleScene(fr)
+    g = lib.Scene(fr)
+    rays = scene_rays(o, cam, 1 << 14, 1 << 14)
+    ref, cnt = o.intersect(rays, counters=True)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_hits = torch.empty((len(rays), 8), dtype=torch.float32, device="cuda")
+    got_cnt = g.intersect_count(d_rays.data_ptr(), len(rays), d_hits.data_ptr())
+    assert (got_cnt == cnt).all(), (got_cnt, cnt)
+    got = d_hits.cpu().numpy().view(abi.hit_dtype).reshape(-1)
+    assert_hits_equal(got, ref, "count variant")
+    # same rays through the asynchronous device-pointer entry point on torch's stream
+    d_hits.zero_()
+    g.intersect_dev(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert_hits_equal(d_hits.cpu().numpy().view(abi.hit_dtype).reshape(-1), ref, "dev variant")
+
+
+def test_edge_cases():
+    fr = mixed_scene(seed=2, n_each=10).freeze()
+    g = lib.Scene(fr)
+    o = orc.OracleScene(fr)
+    # empty batch
+    assert len(g.intersect(np.zeros(0, dtype=abi.ray_dtype))) == 0
+    # ragged batch sizes around the wave and block sizes
+    wb = o.world_bound()
+    for n in (1, 63, 64, 65, 255, 257, 1000):
+        rays = random_rays(n, wb[:3], wb[3:], n)
+        assert_hits_equal(g.intersect(rays), o.intersect(rays), "n=%d" % n)
+    # degenerate rays: zero t_max, negative t_max, NaN direction, zero direction
+    rays = random_rays(8, wb[:3], wb[3:], 1)
+    rays["t_max"][:2] = 0.0
+    rays["t_max"][2] = -1.0
+    rays["d"][3] = np.nan
+    rays["d"][4] = 0.0
+    assert_hits_equal(g.intersect(rays), o.intersect(rays), "degenerate")
+    # rays along the shared edge of the watertight triangle pair: exactly one hit
+    rays = np.zeros(64, dtype=abi.ray_dtype)
+    s = np.linspace(-2.9, 2.9, 64, dtype=np.float32)
+    rays["o"] = np.stack([s, s, np.full(64, 5.0, np.float32)], axis=1)
+    rays["d"] = (0.0, 0.0, -1.0)
+    rays["t_max"] = np.inf
+    got, ref = g.intersect(rays), o.intersect(rays)
+    assert_hits_equal(got, ref, "shared edge")
+
+
+def test_empty_scene():
+    from raytracer_amd.scene import SceneData
+    fr = SceneData().freeze()
+    g = lib.Scene(fr)
+    assert g.info().n_nodes == 0
+    wb = g.world_bound()
+    assert (wb[:3] > wb[3:]).all()  # Bounds3::ZERO
+    rays = random_rays(100, (-1, -1, -1), (1, 1, 1), 0)
+    hits = g.intersect(rays)
+    assert (hits["prim"] == abi.RT_MISS).all() and np.isinf(hits["t"]).all()
+    assert not g.does_intersect(rays).any()
+
+
+def test_generate_rays_match(scene_cache):
+    for name in ("random", "week", "pbrt"):
+        sd, cam, fr = scene_cache(name)
+        c = cam(320, 200)
+        opts = orc.render_opts(320, 200, 4, seed=9)
+        ref = orc.generate_rays(c, opts, 1000, 50000)
+        got = lib.generate_rays(c, opts, 1000, 50000)
+        assert ref.tobytes() == got.tobytes(), name
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("random", 160, 96, 4), ("cornell", 96, 96, 4),
+                                          ("week", 128, 128, 4), ("pbrt", 96, 96, 4)])
+def test_render_bit_exact(scene_cache, name, w, h, spp):
+    sd, cam, fr = scene_cache(name)
+    o, g = orc.OracleScene(fr), lib.Scene(fr)
+    c = cam(w, h)
+    ref, rs = o.render(c, orc.render_opts(w, h, spp, 50, seed=1, flags=abi.RT_RENDER_COUNTERS))
+    got, gs = g.render(c, lib.render_opts(w, h, spp, 50, seed=1, flags=abi.RT_RENDER_COUNTERS))
+    assert gs.paths == rs.paths == w * h * spp
+    assert gs.segments == rs.segments
+    assert gs.nodes_visited == rs.nodes_visited
+    assert list(gs.prims_tested) == list(rs.prims_tested)
+    assert np.isfinite(got).all()
+    assert got.tobytes() == ref.tobytes(), "max abs diff %g" % np.abs(got - ref).max()
+    # small batches (several sample ranges per pixel) give the same image
+    got2, _ = g.render(c, lib.render_opts(w, h, spp, 50, seed=1, max_paths=w * h))
+    assert got2.tobytes() == ref.tobytes()
+
+
+def test_render_mixed_and_sharded():
+    fr = mixed_scene(seed=4, n_each=30).freeze()
+    from raytracer_amd.scene import look_at, perspective_camera
+    w, h, spp = 100, 70, 3
+    c = perspective_camera(w, h, 50.0, look_at((0, 3, -30), (0, 0, 0), (0, 1, 0)), lens_radius=0.2,
+                           focal_distance=30.0, shutter=(0.0, 1.0))
+    o, g = orc.OracleScene(fr), lib.Scene(fr)
+    ref, _ = o.render(c, orc.render_opts(w, h, spp, 12, seed=7))
+    got, _ = g.render(c, lib.render_opts(w, h, spp, 12, seed=7))
+    assert got.tobytes() == ref.tobytes()
+    # tile sharding: the shards' images add up to the whole frame, bit for bit
+    total = np.zeros_like(got)
+    for k in range(3):
+        part, st = g.render(c, lib.render_opts(w, h, spp, 12, seed=7, shard=(k, 3)))
+        assert ((total[..., 3] == 0) | (part[..., 3] == 0)).all()  # disjoint ownership
+        total += part
+    assert total.tobytes() == ref.tobytes()
+
+
+def test_full_size_properties(scene_cache):
+    """BASELINE-size frame (week scene, 1920x1080): checked through properties that do
+    not need the oracle at full size -- a sample of its paths against the oracle,
+    determinism, and independence of the batch size."""
+    sd, cam, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp = 1920, 1080, 2
+    c = cam(w, h)
+    a, sa = g.render(c, lib.render_opts(w, h, spp, 50, seed=0))
+    b, sb = g.render(c, lib.render_opts(w, h, spp, 50, seed=0, max_paths=1 << 21))
+    assert a.tobytes() == b.tobytes() and sa.segments == sb.segments
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all()
+    # 200 pixels spread over the frame: oracle radiance of their paths, summed in order
+    rng = np.random.default_rng(0)
+    opts = orc.render_opts(w, h, spp, 50, seed=0)
+    for pix in rng.integers(0, w * h, 200):
+        rgb, _ = o.path_radiance(c, opts, int(pix) * spp, spp)
+        acc = np.zeros(3, np.float32)
+        for s in range(spp):
+            acc = acc + rgb[s]
+        exp = acc / np.float32(spp)
+        assert (a[pix // w, pix % w, :3] == exp).all(), pix
