@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame of the Next-Week scene
+(test/week.toml of the reference) at 1920x1080, 64 spp, depth 50.
+
+One step = one frame through the HIP wavefront path tracer (rt_render_dev):
+generate -> [closest hit -> shade -> compact] x depth -> resolve.  The scene
+(BVH + primitive tables + textures) is built on the host and uploaded to HBM
+before the timed region; camera rays are generated on the device, so nothing
+crosses PCIe inside it.
+
+With N > 1 (launched by torch.distributed.run, one process per GPU) the frame's
+32x32 tiles are dealt round-robin to the ranks, every rank renders its tiles
+into a zeroed full-size framebuffer and one RCCL reduce(sum) to rank 0 ends the
+frame: total work is fixed, so scaling is "strong".
+
+Extra objects on the JSON line:
+  roofline     -- the bounce kernel (k_bounce): algorithmic bytes of all ray
+                  segments of a frame (traversal counters of an untimed counting
+                  frame; identical to the oracle's) over the summed duration of
+                  the frame's bounce launches, measured with HIP events recorded
+                  on the launch stream inside the timed steps.
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm, not the
+                  product) timed on the host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 50
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# algorithmic bytes: ray read + hit/next-ray write + 32 B per node visited + record per primitive tested
+RAY_BYTES, OUT_BYTES, NODE_BYTES = 32, 32, 32
+PRIM_BYTES = [16, 32, 36, 24, 24, 124, 32, 0]  # sphere, moving, triangle, rect, box, gsphere, medium
+
+
+def algorithmic_bytes(stats):
+    b = stats.segments * (RAY_BYTES + OUT_BYTES) + stats.nodes_visited * NODE_BYTES
+    for k in range(8):
+        b += stats.prims_tested[k] * PRIM_BYTES[k]
+    return int(b)
+
+
+def cpu_baseline(frozen, cam, threads, target_s=15.0):
+    """Oracle (port of the reference path) on the host cores, bounded sample:
+    the same 1920x1080 frame at fewer samples per pixel."""
+    from tests import orc
+    o = orc.OracleScene(frozen)
+    t0 = time.time()
+    _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, 1, DEPTH, seed=0), threads=threads)
+    t1 = time.time() - t0
+    spp = max(1, min(16, int(target_s / max(t1, 1e-3))))
+    t0 = time.time()
+    _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, spp, DEPTH, seed=0), threads=threads)
+    dt = time.time() - t0
+    return {"value": round(st.segments / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+            "kind": "port", "sample": "week scene %dx%d, %d of %d spp, depth %d (%.1f s)" % (
+                WIDTH, HEIGHT, spp, SPP, DEPTH, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help="debug only; the headline is 64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import abi, lib, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sd, camf = scenes.next_week()
+    frozen = sd.freeze()
+    cam = camf(WIDTH, HEIGHT)
+    scene = lib.Scene(frozen, 4, abi.RT_SPLIT_SAH, device=local_rank)
+    scene.upload()
+    info = scene.info()
+    fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def frame(flags=0):
+        opts = lib.render_opts(WIDTH, HEIGHT, args.spp, DEPTH, seed=0, shard=(rank, world), flags=flags)
+        st = scene.render_dev(cam, opts, fb.data_ptr(), stream)
+        if world > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    counted = frame(abi.RT_RENDER_COUNTERS)  # untimed: traversal counters of this rank's shard
+    for _ in range(args.warmup):
+        frame()
+    fence()
+    t0 = time.perf_counter()
+    segments = 0
+    trace_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        st = frame(abi.RT_RENDER_TIMING)
+        segments += st.segments
+        trace_ms += st.trace_ms
+        launches += st.trace_launches
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        t_max = tot[:1].clone()
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        seg_sum = tot[1:].clone()
+        dist.all_reduce(seg_sum, op=dist.ReduceOp.SUM)
+        elapsed, segments = float(t_max.item()), float(seg_sum.item())
+
+    if rank == 0:
+        alg_bytes = algorithmic_bytes(counted)  # per frame, this rank's shard
+        per_launch_ms = trace_ms / max(launches, 1)
+        launches_per_frame = launches / max(args.steps, 1)
+        achieved = alg_bytes / (trace_ms / args.steps * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(segments / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "week.toml Next-Week scene %dx%d %d spp depth %d, %d primitives, "
+                                   "%d BVH nodes (SAH)" % (WIDTH, HEIGHT, args.spp, DEPTH, info.n_prims,
+                                                           info.n_nodes),
+                       "sharding": "32x32 tiles round-robin over ranks, one reduce(sum) per frame",
+                       "ray_segments_per_frame": int(segments / args.steps)},
+            "roofline": {"kernel": "k_bounce", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes / max(launches_per_frame, 1)),
+                         "avg_launch_ms": round(per_launch_ms, 4),
+                         "launches_per_frame": launches_per_frame,
+                         "note": "scene (%.1f MB) is L2/Infinity-Cache resident; bytes are algorithmic" % (
+                             info.device_bytes / 1e6)},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(
+                16, len(os.sched_getaffinity(0)))
+            out["cpu_baseline"] = cpu_baseline(frozen, cam, threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
