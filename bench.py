@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="debug only; the headline is 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,10 @@ def main():
         torch.cuda.synchronize()
 
     counted = frame(abi.RT_RENDER_COUNTERS)  # untimed: traversal counters of this rank's shard
+    if args.verbose and rank == 0:
+        print("bounce_rays", list(counted.bounce_rays[:DEPTH]), file=sys.stderr)
+        print("nodes_visited", counted.nodes_visited, "prims_tested", list(counted.prims_tested),
+              "segments", counted.segments, file=sys.stderr)
     for _ in range(args.warmup):
         frame()
     fence()

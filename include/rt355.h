@@ -258,6 +258,7 @@ typedef struct rt_stats {
     double total_ms; /* first launch -> framebuffer resolved, device time        */
     uint32_t batches;
     uint32_t max_bounce;
+    uint64_t bounce_rays[64]; /* ray segments traced at bounce 0..63 */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

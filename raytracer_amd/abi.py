@@ -95,7 +95,7 @@ class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("prims_tested", C.c_uint64 * 8), ("trace_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("total_ms", C.c_double), ("batches", C.c_uint32),
-                ("max_bounce", C.c_uint32)]
+                ("max_bounce", C.c_uint32), ("bounce_rays", C.c_uint64 * 64)]
 
 
 # sizeof() table in the order rt_abi_sizes() reports it

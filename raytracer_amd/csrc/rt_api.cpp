@@ -85,20 +85,16 @@ struct DeviceBuffers {
     std::vector<void *> allocs;
     rt::SceneDev dev{};
     uint32_t grid = 0;
-    uint32_t *cursors = nullptr; // ring of work cursors for intersect / occluded launches
     unsigned long long *counters = nullptr;
-    std::atomic<uint32_t> next_cursor{0};
     uint64_t bytes = 0;
     // render workspace (grown on demand)
     std::mutex render_lock;
     uint32_t ws_paths = 0, ws_depth = 0;
     rt::Queue q[2]{};
     float4 *radiance = nullptr;
-    uint32_t *counts = nullptr, *bounce_cursors = nullptr;
+    uint32_t *counts = nullptr;
     std::vector<void *> ws_allocs;
 };
-
-constexpr uint32_t kCursorRing = 1024;
 
 } // namespace
 
@@ -370,9 +366,6 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     memcpy(D.background, s.background, sizeof D.background);
 
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, kCursorRing * sizeof(uint32_t)));
-    db.allocs.push_back(p);
-    db.cursors = static_cast<uint32_t *>(p);
     HIP_TRY(hipMalloc(&p, 16 * sizeof(unsigned long long)));
     db.allocs.push_back(p);
     db.counters = static_cast<unsigned long long *>(p);
@@ -415,9 +408,9 @@ int get_device(rt_scene *s, int device, DeviceBuffers **out) {
 
 uint32_t stack_slots(const rt_scene *s) { return s->tree.max_depth ? s->tree.max_depth : 1; }
 
-uint32_t *take_cursor(DeviceBuffers &db) { return db.cursors + (db.next_cursor++ % kCursorRing); }
-
 constexpr size_t kChunk = 1u << 28; // rays per launch (32-bit indices in the kernels)
+
+size_t count_words(uint32_t depth) { return (size_t)(depth + 2) * rt::kShards * rt::kCountStride; }
 
 int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
     if (paths <= db.ws_paths && depth <= db.ws_depth) return RT_OK;
@@ -430,15 +423,19 @@ int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
         return RT_OK;
     };
     int rc;
+    // sub-queue capacity: its share of the 64-path chunks, rounded up
+    const uint32_t chunks = (paths + 63) / 64;
+    const uint32_t cap = (chunks + rt::kShards - 1) / rt::kShards * 64;
+    const size_t entries = (size_t)cap * rt::kShards;
     for (int k = 0; k < 2; k++) {
-        if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.q[k].a))) return rc;
-        if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.q[k].b))) return rc;
-        if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.q[k].c))) return rc;
-        if ((rc = take((size_t)paths * sizeof(uint2), (void **)&db.q[k].d))) return rc;
+        if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].a))) return rc;
+        if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].b))) return rc;
+        if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].c))) return rc;
+        if ((rc = take(entries * sizeof(uint2), (void **)&db.q[k].d))) return rc;
+        db.q[k].cap = cap;
     }
     if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.radiance))) return rc;
-    if ((rc = take((size_t)(depth + 2) * sizeof(uint32_t), (void **)&db.counts))) return rc;
-    if ((rc = take((size_t)(depth + 2) * sizeof(uint32_t), (void **)&db.bounce_cursors))) return rc;
+    if ((rc = take(count_words(depth) * sizeof(uint32_t), (void **)&db.counts))) return rc;
     db.ws_paths = paths;
     db.ws_depth = depth;
     return RT_OK;
@@ -569,10 +566,8 @@ int rt_intersect_dev(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        uint32_t *cur = take_cursor(*db);
-        HIP_TRY(hipMemsetAsync(cur, 0, sizeof(uint32_t), st));
-        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at, cur,
-                                     nullptr, st));
+        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at, nullptr,
+                                     st));
     }
     return RT_OK;
 }
@@ -587,9 +582,7 @@ int rt_intersect_count(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hi
     HIP_TRY(hipMemset(db->counters, 0, 16 * sizeof(unsigned long long)));
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        uint32_t *cur = take_cursor(*db);
-        HIP_TRY(hipMemsetAsync(cur, 0, sizeof(uint32_t), nullptr));
-        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at, cur,
+        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at,
                                      db->counters, nullptr));
     }
     HIP_TRY(hipMemcpy(out, db->counters, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -604,9 +597,7 @@ int rt_occluded_dev(rt_scene *s, const rt_ray *d_rays, size_t n, uint8_t *d_out,
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        uint32_t *cur = take_cursor(*db);
-        HIP_TRY(hipMemsetAsync(cur, 0, sizeof(uint32_t), st));
-        HIP_TRY(rt::launch_occluded(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_out + at, cur, st));
+        HIP_TRY(rt::launch_occluded(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_out + at, st));
     }
     return RT_OK;
 }
@@ -696,7 +687,12 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     const uint32_t tiles = F.tiles_x * ((o->height + 31) / 32);
     const uint32_t my_tiles = tiles > o->shard_index ? (tiles - o->shard_index + shard_count - 1) / shard_count : 0;
     const uint32_t n_ranks = my_tiles * 1024;
-    uint32_t max_paths = o->max_paths ? o->max_paths : (1u << 24);
+    uint32_t owned_pixels = 0; // pixels of this shard that lie inside the image
+    for (uint32_t t = o->shard_index; t < tiles; t += shard_count) {
+        uint32_t tx = t % F.tiles_x, ty = t / F.tiles_x;
+        owned_pixels += std::min(32u, o->width - tx * 32) * std::min(32u, o->height - ty * 32);
+    }
+    uint32_t max_paths = o->max_paths ? o->max_paths : (1u << 27);
     if (max_paths < 1024) max_paths = 1024;
     // samples per batch: as many as fit, all pixels of the shard in every batch
     uint32_t s_batch = n_ranks ? max_paths / n_ranks : 1;
@@ -718,14 +714,14 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     HIP_TRY(hipEventRecord(ev_begin, st));
     uint64_t segments = 0, paths = 0, launches = 0;
     uint32_t batches = 0, max_bounce = 0;
-    std::vector<uint32_t> counts(o->max_depth + 2);
+    std::vector<uint32_t> counts(count_words(o->max_depth));
+    std::vector<uint64_t> per_bounce(o->max_depth, 0);
     for (uint32_t s0 = 0; s0 < o->spp && n_ranks; s0 += s_batch, batches++) {
         const uint32_t sc = std::min(s_batch, o->spp - s0);
         const uint32_t n_local = n_ranks * sc;
-        HIP_TRY(hipMemsetAsync(db->counts, 0, (o->max_depth + 2) * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(db->bounce_cursors, 0, (o->max_depth + 2) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(db->counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(db->radiance, 0, (size_t)n_local * sizeof(float4), st));
-        HIP_TRY(rt::launch_generate(F, *cam, db->q[0], &db->counts[0], n_local, s0, sc, st));
+        HIP_TRY(rt::launch_generate(F, *cam, db->q[0], db->counts, n_local, s0, sc, st));
         for (uint32_t b = 0; b < o->max_depth; b++) {
             if (want_timing) {
                 hipEvent_t e0, e1;
@@ -736,21 +732,26 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 ev.push_back(e1);
             }
             HIP_TRY(rt::launch_bounce(db->dev, stack_slots(s), db->grid, db->q[b & 1], db->q[(b + 1) & 1],
-                                      db->counts, db->bounce_cursors, b, o->max_depth - 1, o->seed,
-                                      db->radiance, want_counters ? db->counters : nullptr, st));
+                                      db->counts, b, o->max_depth - 1, o->seed, db->radiance,
+                                      want_counters ? db->counters : nullptr, st));
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
             launches++;
         }
         HIP_TRY(rt::launch_resolve(F, db->radiance, n_ranks, sc, s0 + sc >= o->spp ? 1 : 0,
                                    reinterpret_cast<float4 *>(d_rgba), st));
         // queue sizes of this batch = ray segments traced per bounce
-        HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, (o->max_depth + 1) * sizeof(uint32_t),
+        HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, counts.size() * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        paths += counts[0];
+        const uint64_t live = (uint64_t)owned_pixels * sc; // entries of bounce 0 that are not padding
+        paths += live;
         for (uint32_t b = 0; b < o->max_depth; b++) {
-            segments += counts[b];
-            if (counts[b] && b > max_bounce) max_bounce = b;
+            uint64_t q = 0;
+            for (uint32_t k = 0; k < rt::kShards; k++) q += counts[((size_t)b * rt::kShards + k) * rt::kCountStride];
+            if (b == 0) q = live;
+            per_bounce[b] += q;
+            segments += q;
+            if (q && b > max_bounce) max_bounce = b;
         }
     }
     HIP_TRY(hipEventRecord(ev_end, st));
@@ -762,6 +763,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         stats->trace_launches = launches;
         stats->batches = batches;
         stats->max_bounce = max_bounce;
+        for (uint32_t b = 0; b < o->max_depth && b < 64; b++) stats->bounce_rays[b] = per_bounce[b];
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->total_ms = ms;

@@ -2,28 +2,33 @@
 // ray generation, the fused trace + shade + compact bounce kernel and the
 // framebuffer resolve.
 //
-// Execution shape: persistent workgroups of 256 threads (4 waves of 64).  Each
-// wave claims 64 rays at a time from a global cursor, so a launch is a fixed
-// grid of (CUs x resident blocks) however many rays are queued.  A lane's
-// traversal stack lives in LDS as stack[level * 256 + thread]: consecutive
-// lanes hit consecutive banks, so pushes and pops are conflict free.
+// Execution shape: persistent workgroups of 256 threads (4 waves of 64); a
+// launch is a fixed grid of (CUs x resident blocks) however many rays are
+// queued, and wave w of W works on the 64-ray chunks w, w + W, w + 2W, ...
+// A lane's traversal stack lives in LDS as stack[level * 256 + thread]:
+// consecutive lanes hit consecutive banks, so pushes and pops are conflict
+// free.
+//
+// Bounce queues are split into kShards independent sub-queues.  A chunk read
+// from shard s appends its survivors to shard s of the next queue: one
+// ballot + prefix count + one atomic per wave, and the atomics of a launch
+// spread over kShards counters that sit on separate cache lines instead of
+// serialising on one word.  Because blocks are dealt round-robin to the 8
+// XCDs and the wave count is a multiple of kShards, every XCD keeps to its
+// own 4 shards from one bounce to the next.
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 
 namespace rt {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kDead = 0xFFFFFFFFu;
 
 RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-
-// Claims `count` consecutive slots at *cursor for the whole wave with one atomic.
-RT_DEV uint32_t wave_claim(uint32_t *cursor, uint32_t count) {
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, count);
-    return __builtin_amdgcn_readfirstlane(base);
-}
+RT_DEV uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
+RT_DEV uint32_t wave_total() { return gridDim.x * (kBlock / 64); }
 
 struct Counters {
     uint32_t nodes;
@@ -35,7 +40,7 @@ struct Counters {
 // Returns the leaf slot of the winning primitive or RT_MISS.
 template <bool ANY, bool COUNT>
 RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0, float &a1, float &a2,
-                         Counters *cnt) {
+                         Counters &cnt) {
     if (S.n_nodes == 0) return RT_MISS;
     v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
     bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
@@ -43,7 +48,7 @@ RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0
     for (;;) {
         float4 n0 = S.nodes[2 * (size_t)cur];
         float4 n1 = S.nodes[2 * (size_t)cur + 1];
-        if (COUNT) cnt->nodes++;
+        if (COUNT) cnt.nodes++;
         bool go_pop = true;
         if (slab(n0, n1, ray, inv, negx, negy, negz)) {
             uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
@@ -52,7 +57,11 @@ RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0
                 for (uint32_t i = 0; i < count; i++) {
                     LeafPrim lp = S.leaf[off + i];
                     float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-                    if (COUNT) cnt->prims[lp.kind & 7u]++;
+                    if (COUNT) {
+                        uint32_t k = lp.kind & 7u;
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
+                    }
                     if (prim_test(S, lp, ray, t, b0, b1, b2)) {
                         if (ANY) return off + i;
                         ray.t_max = t;
@@ -104,21 +113,19 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_intersect(SceneDev S, const rt_ray *rays, uint32_t n,
-                                                      rt_hit *hits, uint32_t *cursor,
-                                                      unsigned long long *counters) {
+                                                      rt_hit *hits, unsigned long long *counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
+    const uint32_t stride = wave_total() * 64;
     Counters cnt = {};
-    for (;;) {
-        uint32_t base = wave_claim(cursor, 64);
-        if (base >= n) break;
+    for (uint32_t base = wave_index() * 64; base < n; base += stride) {
         uint32_t i = base + lane;
         if (i < n) {
             Ray ray = load_ray(rays, i);
             const Ray ray0 = ray;
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, &cnt);
+            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, cnt);
             float4 h0, h1;
             if (slot != RT_MISS) {
                 LeafPrim lp = S.leaf[slot];
@@ -140,18 +147,18 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneDev S, const rt_ray *
 
 // <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
 __global__ __launch_bounds__(kBlock) void k_occluded(SceneDev S, const rt_ray *rays, uint32_t n,
-                                                     uint8_t *out, uint32_t *cursor) {
+                                                     uint8_t *out) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
-        uint32_t base = wave_claim(cursor, 64);
-        if (base >= n) break;
+    const uint32_t stride = wave_total() * 64;
+    Counters cnt = {};
+    for (uint32_t base = wave_index() * 64; base < n; base += stride) {
         uint32_t i = base + lane;
         if (i < n) {
             Ray ray = load_ray(rays, i);
             float a0, a1, a2;
-            uint32_t slot = traverse<true, false>(S, ray, stack, a0, a1, a2, nullptr);
+            uint32_t slot = traverse<true, false>(S, ray, stack, a0, a1, a2, cnt);
             out[i] = slot != RT_MISS ? 1 : 0;
         }
     }
@@ -213,12 +220,9 @@ RT_DEV Ray camera_ray(const rt_camera &cam, float fx, float fy, float lu, float 
     return r;
 }
 
-// path = pixel * spp + sample; PCG32 sequence = seed * 2^32 + path; draws: film x, film y,
-// time, lens u, lens v
-RT_DEV Ray path_setup(const rt_camera &cam, uint32_t width, uint32_t spp, uint64_t seed, uint64_t path,
-                      Rng &rng) {
-    uint64_t pixel = path / spp;
-    uint32_t px = (uint32_t)(pixel % width), py = (uint32_t)(pixel / width);
+// Path of pixel (px, py), global id `path` = pixel * spp + sample; PCG32 sequence =
+// seed * 2^32 + path; draws: film x, film y, time, lens u, lens v.
+RT_DEV Ray path_setup(const rt_camera &cam, uint32_t px, uint32_t py, uint64_t seed, uint64_t path, Rng &rng) {
     rng_seq(rng, (seed << 32) + path);
     float u1 = rng_f(rng), u2 = rng_f(rng), ut = rng_f(rng);
     float l1 = rng_f(rng), l2 = rng_f(rng);
@@ -231,32 +235,23 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(rt_camera cam, uint32_
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Rng rng;
-    Ray r = path_setup(cam, width, spp, seed, first + i, rng);
+    uint64_t path = first + i, pixel = path / spp;
+    Ray r = path_setup(cam, (uint32_t)(pixel % width), (uint32_t)(pixel / width), seed, path, rng);
     float4 *o = reinterpret_cast<float4 *>(rays + i);
     o[0] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
     o[1] = make_float4(r.d.y, r.d.z, r.t_max, r.time);
 }
 
 // ---- bounce queues ------------------------------------------------------------------------------
-RT_DEV void queue_push(const Queue &q, uint32_t slot, const Ray &r, uint32_t local, v3 beta,
-                       const Rng &rng, uint32_t gpath) {
+RT_DEV void queue_push(const Queue &q, size_t slot, const Ray &r, uint32_t local, v3 beta, const Rng &rng,
+                       uint32_t gpath) {
     q.a[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
     q.b[slot] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(local));
     q.c[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
     q.d[slot] = make_uint2((uint32_t)(rng.state >> 32), gpath);
 }
 
-// Appends the lanes with `alive` set to the queue: ballot, rank by prefix count,
-// one atomic per wave for the tail (stream compaction).
-RT_DEV uint32_t compact_slot(bool alive, uint32_t *tail) {
-    uint64_t mask = __ballot(alive);
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    if (total) base = wave_claim(tail, total);
-    return base + lane_rank(mask);
-}
-
-// pixel owned by this shard with rank r: 32x32 tiles, tile t = shard_index + k * shard_count
+// pixel owned by this shard of the frame with rank r: 32x32 tiles, tile t = shard_index + k * shard_count
 RT_DEV bool rank_to_pixel(const FrameDev &F, uint32_t rank, uint32_t &px, uint32_t &py) {
     uint32_t tile = F.shard_index + (rank >> 10) * F.shard_count;
     uint32_t within = rank & 1023u;
@@ -266,9 +261,19 @@ RT_DEV bool rank_to_pixel(const FrameDev &F, uint32_t rank, uint32_t &px, uint32
     return px < F.width && py < F.height;
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, Queue q, uint32_t *tail,
+// Primary rays, written in place: path `local` goes to chunk local / 64, chunk c to
+// sub-queue c % kShards.  Pixels outside the image (partial edge tiles) leave a dead entry.
+__global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, Queue q, uint32_t *counts,
                                                      uint32_t n_local, uint32_t s0, uint32_t s_count) {
-    uint32_t local = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_chunks = (n_local + 63) / 64;
+    if (blockIdx.x == 0 && threadIdx.x < kShards) {
+        uint32_t s = threadIdx.x;
+        counts[s * kCountStride] = s < n_chunks ? 64u * ((n_chunks - s + kShards - 1) / kShards) : 0u;
+    }
+    const uint32_t chunk = local >> 6;
+    if (chunk >= n_chunks) return;
+    const size_t slot = (size_t)(chunk % kShards) * q.cap + (size_t)(chunk / kShards) * 64 + (local & 63u);
     bool alive = false;
     Ray ray;
     Rng rng;
@@ -277,12 +282,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, 
         uint32_t rank = local / s_count, s = s0 + local % s_count, px, py;
         if (rank_to_pixel(F, rank, px, py)) {
             gpath = (py * F.width + px) * F.spp + s;
-            ray = path_setup(cam, F.width, F.spp, F.seed, gpath, rng);
+            ray = path_setup(cam, px, py, F.seed, gpath, rng);
             alive = true;
         }
     }
-    uint32_t slot = compact_slot(alive, tail);
-    if (alive) queue_push(q, slot, ray, local, mk(1.0f, 1.0f, 1.0f), rng, gpath);
+    if (alive) {
+        queue_push(q, slot, ray, local, mk(1.0f, 1.0f, 1.0f), rng, gpath);
+    } else {
+        q.b[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kDead));
+    }
 }
 
 // ---- textures -----------------------------------------------------------------------------------
@@ -380,41 +388,50 @@ RT_DEV v3 offset_origin(v3 p, v3 err, v3 n, v3 w) {
 // path ends on a light or leaves the scene.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue qout, uint32_t *counts,
-                                                   uint32_t *cursors, uint32_t bounce, uint32_t last,
-                                                   uint64_t seed, float4 *radiance,
-                                                   unsigned long long *counters) {
+                                                   uint32_t bounce, uint32_t last, uint64_t seed,
+                                                   float4 *radiance, unsigned long long *counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n = counts[bounce];
+    const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
+    uint32_t *cout = counts + (size_t)(bounce + 1) * kShards * kCountStride;
+    // lane s holds the size of sub-queue s; the longest one bounds the chunk loop
+    const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
+    uint32_t longest = my_count;
+    for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
+    const uint32_t n_chunks = kShards * ((longest + 63) / 64);
     Counters cnt = {};
-    for (;;) {
-        uint32_t base = wave_claim(&cursors[bounce], 64);
-        if (base >= n) break;
-        uint32_t i = base + lane;
+    for (uint32_t c = wave_index(); c < n_chunks; c += wave_total()) {
+        const uint32_t shard = c % kShards;
+        const uint32_t i = (c / kShards) * 64 + lane;
+        const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
+        const size_t in_base = (size_t)shard * qin.cap;
         bool alive = false;
         Ray ray;
         Rng rng;
         v3 beta = mk(0.0f, 0.0f, 0.0f);
-        uint32_t local = 0, gpath = 0;
+        uint32_t local = kDead, gpath = 0;
         if (i < n) {
-            float4 qa = qin.a[i], qb = qin.b[i], qc = qin.c[i];
-            uint2 qd = qin.d[i];
-            ray.o = mk(qa.x, qa.y, qa.z);
-            ray.time = qa.w;
-            ray.d = mk(qb.x, qb.y, qb.z);
-            ray.t_max = kInf;
+            float4 qb = qin.b[in_base + i];
             local = __float_as_uint(qb.w);
-            beta = mk(qc.x, qc.y, qc.z);
-            gpath = qd.y;
-            rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
-            rng.inc = (((seed << 32) + gpath) << 1) | 1u;
-            alive = true;
+            if (local != kDead) {
+                float4 qa = qin.a[in_base + i], qc = qin.c[in_base + i];
+                uint2 qd = qin.d[in_base + i];
+                ray.o = mk(qa.x, qa.y, qa.z);
+                ray.time = qa.w;
+                ray.d = mk(qb.x, qb.y, qb.z);
+                ray.t_max = kInf;
+                beta = mk(qc.x, qc.y, qc.z);
+                gpath = qd.y;
+                rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
+                rng.inc = (((seed << 32) + gpath) << 1) | 1u;
+                alive = true;
+            }
         }
         if (alive) {
             const Ray ray0 = ray;
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, &cnt);
+            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, cnt);
             if (slot == RT_MISS) {
                 radiance[local] = make_float4(beta.x * S.background[0], beta.y * S.background[1],
                                               beta.z * S.background[2], 0.0f);
@@ -457,8 +474,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue 
                     if (!reflect_it) {
                         float r0 = (1.0f - ratio) / (1.0f + ratio);
                         r0 = r0 * r0;
-                        float c = 1.0f - cos_t;
-                        float refl = r0 + (1.0f - r0) * (c * c * c * c * c);
+                        float c5 = 1.0f - cos_t;
+                        float refl = r0 + (1.0f - r0) * (c5 * c5 * c5 * c5 * c5);
                         reflect_it = refl > rng_f(rng);
                     }
                     if (reflect_it) {
@@ -483,8 +500,16 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue 
             }
             if (bounce == last) alive = false; // depth exhausted: the path contributes nothing
         }
-        uint32_t slot = compact_slot(alive, &counts[bounce + 1]);
-        if (alive) queue_push(qout, slot, ray, local, beta, rng, gpath);
+        // stream compaction: ballot, rank by prefix count, one atomic per wave on the shard's tail
+        const uint64_t mask = __ballot(alive);
+        const uint32_t total = (uint32_t)__popcll(mask);
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cout[shard * kCountStride], total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (alive)
+                queue_push(qout, (size_t)shard * qout.cap + base + lane_rank(mask), ray, local, beta, rng, gpath);
+        }
     }
     if (COUNT) flush_counters(cnt, counters);
 }
@@ -518,21 +543,25 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev F, const float4 *ra
 static inline size_t stack_bytes(uint32_t slots) { return (size_t)slots * kBlock * sizeof(uint32_t); }
 
 hipError_t launch_intersect(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
-                            rt_hit *hits, uint32_t *cursor, unsigned long long *counters,
-                            hipStream_t stream) {
+                            rt_hit *hits, unsigned long long *counters, hipStream_t stream) {
+    uint32_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > grid) blocks = grid;
+    if (blocks == 0) return hipSuccess;
     if (counters)
-        hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, rays,
-                           n, hits, cursor, counters);
+        hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(slots), stream, S, rays,
+                           n, hits, counters);
     else
-        hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, rays,
-                           n, hits, cursor, counters);
+        hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(slots), stream, S, rays,
+                           n, hits, counters);
     return hipGetLastError();
 }
 
 hipError_t launch_occluded(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
-                           uint8_t *out, uint32_t *cursor, hipStream_t stream) {
-    hipLaunchKernelGGL(k_occluded, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, rays, n, out,
-                       cursor);
+                           uint8_t *out, hipStream_t stream) {
+    uint32_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > grid) blocks = grid;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_occluded, dim3(blocks), dim3(kBlock), stack_bytes(slots), stream, S, rays, n, out);
     return hipGetLastError();
 }
 
@@ -543,22 +572,23 @@ hipError_t launch_generate_rays(const rt_camera &cam, uint32_t width, uint32_t s
     return hipGetLastError();
 }
 
-hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *tail,
+hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
                            uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream) {
-    hipLaunchKernelGGL(k_generate, dim3((n_local + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, cam, q,
-                       tail, n_local, s0, s_count);
+    uint32_t padded = (n_local + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_generate, dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, cam, q,
+                       counts, n_local, s0, s_count);
     return hipGetLastError();
 }
 
 hipError_t launch_bounce(const SceneDev &S, uint32_t slots, uint32_t grid, const Queue &qin, const Queue &qout,
-                         uint32_t *counts, uint32_t *cursors, uint32_t bounce, uint32_t last, uint64_t seed,
-                         float4 *radiance, unsigned long long *counters, hipStream_t stream) {
+                         uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
+                         unsigned long long *counters, hipStream_t stream) {
     if (counters)
         hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, qin, qout,
-                           counts, cursors, bounce, last, seed, radiance, counters);
+                           counts, bounce, last, seed, radiance, counters);
     else
         hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, qin, qout,
-                           counts, cursors, bounce, last, seed, radiance, counters);
+                           counts, bounce, last, seed, radiance, counters);
     return hipGetLastError();
 }
 
