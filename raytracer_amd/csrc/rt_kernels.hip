@@ -38,52 +38,64 @@ struct Counters {
 // <BVH as Primitive>::intersect, shapes/src/bvh.rs:736-799, with the ray
 // shortened on every accepted hit (ties go to the primitive tested later).
 // Returns the leaf slot of the winning primitive or RT_MISS.
+//
+// Same visiting order per ray as the reference loop, scheduled for a 64-wide
+// wave: every lane first walks interior nodes until it holds a leaf (or runs
+// out of nodes), then the lanes that hold a leaf test its primitives together.
+// The primitive code (a switch over seven kinds) is therefore executed once
+// per leaf round instead of once per node step.
 template <bool ANY, bool COUNT>
 RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0, float &a1, float &a2,
                          Counters &cnt) {
-    if (S.n_nodes == 0) return RT_MISS;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
     bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
-    uint32_t sp = 0, cur = 0, best = RT_MISS;
+    uint32_t sp = 0, cur = S.n_nodes ? 0u : kNone, best = RT_MISS;
     for (;;) {
-        float4 n0 = S.nodes[2 * (size_t)cur];
-        float4 n1 = S.nodes[2 * (size_t)cur + 1];
-        if (COUNT) cnt.nodes++;
-        bool go_pop = true;
-        if (slab(n0, n1, ray, inv, negx, negy, negz)) {
-            uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
-            uint32_t count = meta & 0xffffu;
-            if (count > 0) { // leaf, bvh.rs:763-776
-                for (uint32_t i = 0; i < count; i++) {
-                    LeafPrim lp = S.leaf[off + i];
-                    float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-                    if (COUNT) {
-                        uint32_t k = lp.kind & 7u;
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
-                    }
-                    if (prim_test(S, lp, ray, t, b0, b1, b2)) {
-                        if (ANY) return off + i;
-                        ray.t_max = t;
-                        best = off + i;
-                        a0 = b0; a1 = b1; a2 = b2;
-                    }
+        uint32_t leaf_off = 0, leaf_cnt = 0;
+        while (cur != kNone) { // interior steps, bvh.rs:760-762,778-795
+            float4 n0 = S.nodes[2 * (size_t)cur];
+            float4 n1 = S.nodes[2 * (size_t)cur + 1];
+            if (COUNT) cnt.nodes++;
+            if (slab(n0, n1, ray, inv, negx, negy, negz)) {
+                uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
+                uint32_t count = meta & 0xffffu;
+                if (count > 0) {
+                    leaf_off = off;
+                    leaf_cnt = count;
+                    break;
                 }
-            } else { // interior, bvh.rs:778-787
                 uint32_t axis = meta >> 16;
                 bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                uint32_t far_child = neg ? cur + 1 : off;
-                cur = neg ? off : cur + 1;
-                stack[sp * kBlock] = far_child;
+                stack[sp * kBlock] = neg ? cur + 1 : off; // far child
                 sp++;
-                go_pop = false;
+                cur = neg ? off : cur + 1;
+            } else if (sp == 0) {
+                cur = kNone;
+            } else {
+                sp--;
+                cur = stack[sp * kBlock];
             }
         }
-        if (go_pop) {
-            if (sp == 0) break;
-            sp--;
-            cur = stack[sp * kBlock];
+        if (leaf_cnt == 0) break; // no node left for this ray
+        for (uint32_t i = 0; i < leaf_cnt; i++) { // leaf, bvh.rs:763-771
+            LeafPrim lp = S.leaf[leaf_off + i];
+            float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+            if (COUNT) {
+                uint32_t k = lp.kind & 7u;
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
+            }
+            if (prim_test(S, lp, ray, t, b0, b1, b2)) {
+                if (ANY) return leaf_off + i;
+                ray.t_max = t;
+                best = leaf_off + i;
+                a0 = b0; a1 = b1; a2 = b2;
+            }
         }
+        if (sp == 0) break; // bvh.rs:772-776
+        sp--;
+        cur = stack[sp * kBlock];
     }
     return best;
 }
@@ -440,32 +452,28 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue 
                 LeafPrim lp = S.leaf[slot];
                 Surf h;
                 prim_finalize(S, lp, ray0, ray.t_max, a0, a1, a2, h);
-                v3 d = ray0.d;
-                bool front = dot(d, h.n) < 0.0f;
-                v3 nf = front ? h.n : -h.n;
-                rt_material m = S.materials[lp.material];
+                const v3 d = ray0.d;
+                const bool front = dot(d, h.n) < 0.0f;
+                const v3 nf = front ? h.n : -h.n;
+                const rt_material m = S.materials[lp.material];
+                // The pieces every material shares run once for the whole wave: the
+                // texture lookup (all but dielectrics) and the unit-sphere sample
+                // (Lambertian, metallic, isotropic).  Per path the RNG draws stay in
+                // the same order as when each material is evaluated on its own.
+                v3 tex = mk(1.0f, 1.0f, 1.0f), rs = mk(0.0f, 0.0f, 0.0f);
+                if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
+                    rs = random_in_unit_sphere(rng);
+                if (m.kind != RT_MAT_DIELECTRIC) tex = texture_value(S, m.texture, h.u, h.v, h.p);
                 v3 dir = nf;
                 if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
-                    v3 e = texture_value(S, m.texture, h.u, h.v, h.p);
-                    radiance[local] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
+                    radiance[local] = make_float4(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z, 0.0f);
                     alive = false;
                 } else if (m.kind == RT_MAT_LAMBERTIAN) {
-                    v3 r = random_in_unit_sphere(rng);
-                    dir = nf + r;
+                    dir = nf + rs;
                     if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = nf;
-                    dir = normalize(dir);
-                    v3 a = texture_value(S, m.texture, h.u, h.v, h.p);
-                    beta = mk(beta.x * a.x, beta.y * a.y, beta.z * a.z);
                 } else if (m.kind == RT_MAT_METALLIC) {
-                    v3 r = random_in_unit_sphere(rng);
-                    dir = reflect(d, nf) + r * m.fuzz;
-                    if (!(dot(dir, nf) > 0.0f)) {
-                        alive = false; // absorbed
-                    } else {
-                        dir = normalize(dir);
-                        v3 a = texture_value(S, m.texture, h.u, h.v, h.p);
-                        beta = mk(beta.x * a.x, beta.y * a.y, beta.z * a.z);
-                    }
+                    dir = reflect(d, nf) + rs * m.fuzz;
+                    if (!(dot(dir, nf) > 0.0f)) alive = false; // absorbed
                 } else if (m.kind == RT_MAT_DIELECTRIC) {
                     float ratio = front ? 1.0f / m.ior : m.ior;
                     float cos_t = sel_min(dot(-d, nf), 1.0f);
@@ -486,13 +494,12 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue 
                         v3 par = nf * -sqrtf(fabsf(k));
                         dir = perp + par;
                     }
-                    dir = normalize(dir);
                 } else { // RT_MAT_ISOTROPIC
-                    dir = normalize(random_in_unit_sphere(rng));
-                    v3 a = texture_value(S, m.texture, h.u, h.v, h.p);
-                    beta = mk(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+                    dir = rs;
                 }
                 if (alive) {
+                    dir = normalize(dir);
+                    beta = mk(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z);
                     ray.o = offset_origin(h.p, h.perr, h.n, dir);
                     ray.d = dir;
                     ray.t_max = kInf;

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of rt_intersect_dev / rt_occluded_dev: primary rays (coherent)
+and cosine-distributed bounce rays (incoherent) on one scene, rays resident in
+HBM.  usage: trace_bench.py [scene] [log2 rays] [scene kwargs as k=v]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+
+from raytracer_amd import abi, lib, scenes
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "week"
+    log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[3:])}
+    sd, camf = scenes.BUILDERS[name](**kw)
+    fr = sd.freeze()
+    scene = lib.Scene(fr)
+    scene.upload()
+    info = scene.info()
+    n = 1 << log2n
+    w = 4096
+    h = n // w
+    cam = camf(w, h)
+    opts = lib.render_opts(w, h, 1, seed=0)
+    L = lib.load()
+    import ctypes as C
+    d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_hits = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    # primary rays: generated on the device in pieces through the host API (setup only)
+    piece = 1 << 22
+    for at in range(0, n, piece):
+        r = lib.generate_rays(cam, opts, at, min(piece, n - at))
+        d_rays[at:at + piece] = torch.from_numpy(r.view(np.float32).reshape(-1, 8)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {"scene": name, "prims": info.n_prims, "nodes": info.n_nodes, "rays": n}
+    ms = timed(lambda: scene.intersect_dev(d_rays.data_ptr(), n, d_hits.data_ptr(), stream))
+    cnt = scene.intersect_count(d_rays.data_ptr(), n, d_hits.data_ptr())
+    out["primary"] = {"ms": round(ms, 3), "Mrays_s": round(n / ms / 1e3, 1),
+                      "nodes_per_ray": round(float(cnt[0]) / n, 2),
+                      "prims_per_ray": round(float(cnt[1:].sum()) / n, 2)}
+    ms = timed(lambda: scene.occluded_dev(d_rays.data_ptr(), n, d_occ.data_ptr(), stream))
+    out["primary_any_hit"] = {"ms": round(ms, 3), "Mrays_s": round(n / ms / 1e3, 1)}
+    # bounce rays: from the primary hit points, direction = normal + uniform unit vector
+    hits = d_hits.clone()
+    t = hits[:, 0:1]
+    prim = hits[:, 1].view(torch.int32)
+    nrm = hits[:, 4:7]
+    o, d = d_rays[:, 0:3], d_rays[:, 3:6]
+    hit = (prim != -1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    v = torch.randn((n, 3), device="cuda", generator=g)
+    v = v / v.norm(dim=1, keepdim=True)
+    nf = torch.where((nrm * d).sum(1, keepdim=True) < 0, nrm, -nrm)
+    nd = nf + v
+    nd = nd / nd.norm(dim=1, keepdim=True).clamp_min(1e-20)
+    p = o + t * d + nf * 1e-3 * (1.0 + (o + t * d).abs().amax(1, keepdim=True))
+    b_rays = d_rays.clone()
+    b_rays[:, 0:3] = torch.where(hit[:, None], p, o)
+    b_rays[:, 3:6] = torch.where(hit[:, None], nd, d)
+    b_rays = b_rays[hit].contiguous()
+    m = b_rays.shape[0]
+    ms = timed(lambda: scene.intersect_dev(b_rays.data_ptr(), m, d_hits.data_ptr(), stream))
+    cnt = scene.intersect_count(b_rays.data_ptr(), m, d_hits.data_ptr())
+    out["bounce1"] = {"rays": m, "ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1),
+                      "nodes_per_ray": round(float(cnt[0]) / m, 2),
+                      "prims_per_ray": round(float(cnt[1:].sum()) / m, 2)}
+    ms = timed(lambda: scene.occluded_dev(b_rays.data_ptr(), m, d_occ.data_ptr(), stream))
+    out["bounce1_any_hit"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
