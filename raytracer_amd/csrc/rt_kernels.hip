@@ -22,6 +22,13 @@
 namespace rt {
 
 constexpr int kBlock = 256;
+// minimum resident waves per SIMD the register allocator must leave room for
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4
+#endif
+#ifndef RT_BOUNCE_WAVES
+#define RT_BOUNCE_WAVES 4
+#endif
 constexpr uint32_t kDead = 0xFFFFFFFFu;
 
 RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
@@ -124,7 +131,7 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(SceneDev S, const rt_ray *rays, uint32_t n,
+__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_intersect(SceneDev S, const rt_ray *rays, uint32_t n,
                                                       rt_hit *hits, unsigned long long *counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneDev S, const rt_ray *
 }
 
 // <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
-__global__ __launch_bounds__(kBlock) void k_occluded(SceneDev S, const rt_ray *rays, uint32_t n,
+__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_occluded(SceneDev S, const rt_ray *rays, uint32_t n,
                                                      uint8_t *out) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -399,7 +406,7 @@ RT_DEV v3 offset_origin(v3 p, v3 err, v3 n, v3 w) {
 // survivors compacted into the next queue.  Radiance is stored once, when a
 // path ends on a light or leaves the scene.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_bounce(SceneDev S, Queue qin, Queue qout, uint32_t *counts,
+__global__ __launch_bounds__(kBlock, RT_BOUNCE_WAVES) void k_bounce(SceneDev S, Queue qin, Queue qout, uint32_t *counts,
                                                    uint32_t bounce, uint32_t last, uint64_t seed,
                                                    float4 *radiance, unsigned long long *counters) {
     extern __shared__ uint32_t lds_stack[];

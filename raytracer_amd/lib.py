@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt355.so")
+LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "librt355.so")
 _LIB = None
 
 
