@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -84,7 +85,7 @@ std::vector<T> copy_in(const T *p, size_t n) {
 struct DeviceBuffers {
     std::vector<void *> allocs;
     rt::SceneDev dev{};
-    uint32_t grid = 0;
+    rt::LaunchShape shape{};
     unsigned long long *counters = nullptr;
     uint64_t bytes = 0;
     // render workspace (grown on demand)
@@ -372,13 +373,27 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    // persistent grid: enough 256-thread blocks to fill every CU at the LDS-bound occupancy
-    uint32_t slots = s.tree.max_depth ? s.tree.max_depth : 1;
-    size_t lds = (size_t)slots * 256 * 4;
-    uint32_t per_cu = (uint32_t)(prop.maxSharedMemoryPerMultiProcessor / (lds ? lds : 1));
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    db.grid = (uint32_t)prop.multiProcessorCount * per_cu;
+    // Persistent grid.  If the node array and 16-bit stacks of a 1024-thread workgroup fit in
+    // one CU's LDS the tree is traversed from LDS (one workgroup per CU); otherwise 256-thread
+    // workgroups with 32-bit stacks, as many per CU as the stacks allow.
+    const uint32_t slots = s.tree.max_depth ? s.tree.max_depth : 1;
+    const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor;
+    const size_t lds_tree = nodes.size() * 32 + (size_t)slots * 1024 * sizeof(uint16_t);
+    const char *force = getenv("RT355_NODES"); // "global" or "lds": override for experiments
+    bool lds_nodes = !nodes.empty() && nodes.size() < 65536 && lds_tree <= lds_cu &&
+                     lds_tree <= (size_t)prop.sharedMemPerBlockOptin;
+    if (force && !strcmp(force, "global")) lds_nodes = false;
+    db.shape.slots = slots;
+    db.shape.lds_nodes = lds_nodes;
+    if (lds_nodes) {
+        db.shape.grid = (uint32_t)prop.multiProcessorCount;
+    } else {
+        size_t lds = (size_t)slots * 256 * 4;
+        uint32_t per_cu = (uint32_t)(lds_cu / (lds ? lds : 1));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        db.shape.grid = (uint32_t)prop.multiProcessorCount * per_cu;
+    }
     return RT_OK;
 }
 
@@ -566,7 +581,7 @@ int rt_intersect_dev(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at, nullptr,
+        HIP_TRY(rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at, nullptr,
                                      st));
     }
     return RT_OK;
@@ -582,7 +597,7 @@ int rt_intersect_count(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hi
     HIP_TRY(hipMemset(db->counters, 0, 16 * sizeof(unsigned long long)));
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        HIP_TRY(rt::launch_intersect(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_hits + at,
+        HIP_TRY(rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at,
                                      db->counters, nullptr));
     }
     HIP_TRY(hipMemcpy(out, db->counters, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -597,7 +612,7 @@ int rt_occluded_dev(rt_scene *s, const rt_ray *d_rays, size_t n, uint8_t *d_out,
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        HIP_TRY(rt::launch_occluded(db->dev, stack_slots(s), db->grid, d_rays + at, m, d_out + at, st));
+        HIP_TRY(rt::launch_occluded(db->dev, db->shape, d_rays + at, m, d_out + at, st));
     }
     return RT_OK;
 }
@@ -731,7 +746,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 ev.push_back(e0);
                 ev.push_back(e1);
             }
-            HIP_TRY(rt::launch_bounce(db->dev, stack_slots(s), db->grid, db->q[b & 1], db->q[(b + 1) & 1],
+            HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
                                       db->counts, b, o->max_depth - 1, o->seed, db->radiance,
                                       want_counters ? db->counters : nullptr, st));
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));

@@ -34,8 +34,58 @@ constexpr uint32_t kDead = 0xFFFFFFFFu;
 RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-RT_DEV uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
-RT_DEV uint32_t wave_total() { return gridDim.x * (kBlock / 64); }
+RT_DEV uint32_t wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+RT_DEV uint32_t wave_total() { return gridDim.x * (blockDim.x >> 6); }
+
+// Two launch shapes.  Trees whose nodes fit beside the stacks are copied into
+// LDS by every workgroup (1024 threads, one per CU): incoherent rays then fetch
+// nodes with ds_read_b128 from two separate arrays (lower corner + offset /
+// upper corner + count, so that 16 lanes spread over all 16-byte slots of a
+// bank row) instead of queueing 64 distinct cache lines per load in the vector
+// L1.  Larger trees stay in global memory (256-thread workgroups).
+template <bool LDSN>
+struct Shape;
+template <>
+struct Shape<false> {
+    static constexpr int kThreads = kBlock;
+    static constexpr int kWaves = RT_TRACE_WAVES;
+    using StackT = uint32_t;
+};
+template <>
+struct Shape<true> {
+    static constexpr int kThreads = 1024;
+    static constexpr int kWaves = 4;
+    using StackT = uint16_t;
+};
+
+extern __shared__ float4 lds_raw[];
+
+template <bool LDSN>
+struct TreeView {
+    const float4 *lo, *hi; // LDS copies (LDSN) or unused
+    typename Shape<LDSN>::StackT *stack;
+};
+
+// Carves the dynamic LDS; with LDSN also stages the node array (call from all threads).
+template <bool LDSN>
+RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
+    TreeView<LDSN> v;
+    if constexpr (LDSN) {
+        float4 *lo = lds_raw, *hi = lds_raw + S.n_nodes;
+        for (uint32_t i = threadIdx.x; i < S.n_nodes; i += Shape<true>::kThreads) {
+            lo[i] = S.nodes[2 * (size_t)i];
+            hi[i] = S.nodes[2 * (size_t)i + 1];
+        }
+        __syncthreads();
+        v.lo = lo;
+        v.hi = hi;
+        v.stack = reinterpret_cast<uint16_t *>(lds_raw + 2 * (size_t)S.n_nodes) + threadIdx.x;
+    } else {
+        v.lo = v.hi = nullptr;
+        v.stack = reinterpret_cast<uint32_t *>(lds_raw) + threadIdx.x;
+    }
+    return v;
+}
 
 struct Counters {
     uint32_t nodes;
@@ -51,18 +101,26 @@ struct Counters {
 // out of nodes), then the lanes that hold a leaf test its primitives together.
 // The primitive code (a switch over seven kinds) is therefore executed once
 // per leaf round instead of once per node step.
-template <bool ANY, bool COUNT>
-RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0, float &a1, float &a2,
+template <bool ANY, bool COUNT, bool LDSN>
+RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, float &a0, float &a1, float &a2,
                          Counters &cnt) {
     constexpr uint32_t kNone = 0xFFFFFFFFu;
+    constexpr int kStride = Shape<LDSN>::kThreads;
+    typename Shape<LDSN>::StackT *stack = tv.stack;
     v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
     bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
     uint32_t sp = 0, cur = S.n_nodes ? 0u : kNone, best = RT_MISS;
     for (;;) {
         uint32_t leaf_off = 0, leaf_cnt = 0;
         while (cur != kNone) { // interior steps, bvh.rs:760-762,778-795
-            float4 n0 = S.nodes[2 * (size_t)cur];
-            float4 n1 = S.nodes[2 * (size_t)cur + 1];
+            float4 n0, n1;
+            if constexpr (LDSN) {
+                n0 = tv.lo[cur];
+                n1 = tv.hi[cur];
+            } else {
+                n0 = S.nodes[2 * (size_t)cur];
+                n1 = S.nodes[2 * (size_t)cur + 1];
+            }
             if (COUNT) cnt.nodes++;
             if (slab(n0, n1, ray, inv, negx, negy, negz)) {
                 uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
@@ -74,14 +132,14 @@ RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0
                 }
                 uint32_t axis = meta >> 16;
                 bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                stack[sp * kBlock] = neg ? cur + 1 : off; // far child
+                stack[sp * kStride] = neg ? cur + 1 : off; // far child
                 sp++;
                 cur = neg ? off : cur + 1;
             } else if (sp == 0) {
                 cur = kNone;
             } else {
                 sp--;
-                cur = stack[sp * kBlock];
+                cur = stack[sp * kStride];
             }
         }
         if (leaf_cnt == 0) break; // no node left for this ray
@@ -102,7 +160,7 @@ RT_DEV uint32_t traverse(const SceneDev &S, Ray &ray, uint32_t *stack, float &a0
         }
         if (sp == 0) break; // bvh.rs:772-776
         sp--;
-        cur = stack[sp * kBlock];
+        cur = stack[sp * kStride];
     }
     return best;
 }
@@ -130,11 +188,10 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
     }
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_intersect(SceneDev S, const rt_ray *rays, uint32_t n,
-                                                      rt_hit *hits, unsigned long long *counters) {
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t *stack = lds_stack + threadIdx.x;
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_intersect(
+    SceneDev S, const rt_ray *rays, uint32_t n, rt_hit *hits, unsigned long long *counters) {
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t stride = wave_total() * 64;
     Counters cnt = {};
@@ -144,7 +201,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_intersect(SceneDev S
             Ray ray = load_ray(rays, i);
             const Ray ray0 = ray;
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, cnt);
+            uint32_t slot = traverse<false, COUNT, LDSN>(S, tv, ray, a0, a1, a2, cnt);
             float4 h0, h1;
             if (slot != RT_MISS) {
                 LeafPrim lp = S.leaf[slot];
@@ -165,10 +222,10 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_intersect(SceneDev S
 }
 
 // <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
-__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_occluded(SceneDev S, const rt_ray *rays, uint32_t n,
-                                                     uint8_t *out) {
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t *stack = lds_stack + threadIdx.x;
+template <bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_occluded(
+    SceneDev S, const rt_ray *rays, uint32_t n, uint8_t *out) {
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t stride = wave_total() * 64;
     Counters cnt = {};
@@ -177,7 +234,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_occluded(SceneDev S,
         if (i < n) {
             Ray ray = load_ray(rays, i);
             float a0, a1, a2;
-            uint32_t slot = traverse<true, false>(S, ray, stack, a0, a1, a2, cnt);
+            uint32_t slot = traverse<true, false, LDSN>(S, tv, ray, a0, a1, a2, cnt);
             out[i] = slot != RT_MISS ? 1 : 0;
         }
     }
@@ -405,12 +462,10 @@ RT_DEV v3 offset_origin(v3 p, v3 err, v3 n, v3 w) {
 // One bounce of every queued path: closest hit, shading, scatter, and the
 // survivors compacted into the next queue.  Radiance is stored once, when a
 // path ends on a light or leaves the scene.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_BOUNCE_WAVES) void k_bounce(SceneDev S, Queue qin, Queue qout, uint32_t *counts,
-                                                   uint32_t bounce, uint32_t last, uint64_t seed,
-                                                   float4 *radiance, unsigned long long *counters) {
-    extern __shared__ uint32_t lds_stack[];
-    uint32_t *stack = lds_stack + threadIdx.x;
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) void k_bounce(
+    SceneDev S, Queue qin, Queue qout, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
+    float4 *radiance, unsigned long long *counters) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
     uint32_t *cout = counts + (size_t)(bounce + 1) * kShards * kCountStride;
@@ -419,6 +474,8 @@ __global__ __launch_bounds__(kBlock, RT_BOUNCE_WAVES) void k_bounce(SceneDev S, 
     uint32_t longest = my_count;
     for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
     const uint32_t n_chunks = kShards * ((longest + 63) / 64);
+    if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
     for (uint32_t c = wave_index(); c < n_chunks; c += wave_total()) {
         const uint32_t shard = c % kShards;
@@ -450,7 +507,7 @@ __global__ __launch_bounds__(kBlock, RT_BOUNCE_WAVES) void k_bounce(SceneDev S, 
         if (alive) {
             const Ray ray0 = ray;
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            uint32_t slot = traverse<false, COUNT>(S, ray, stack, a0, a1, a2, cnt);
+            uint32_t slot = traverse<false, COUNT, LDSN>(S, tv, ray, a0, a1, a2, cnt);
             if (slot == RT_MISS) {
                 radiance[local] = make_float4(beta.x * S.background[0], beta.y * S.background[1],
                                               beta.z * S.background[2], 0.0f);
@@ -554,28 +611,52 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev F, const float4 *ra
 }
 
 // ---- host-side launchers ------------------------------------------------------------------------------
-static inline size_t stack_bytes(uint32_t slots) { return (size_t)slots * kBlock * sizeof(uint32_t); }
+// dynamic LDS: stacks only, or nodes + 16-bit stacks for the LDS-resident shape
+static inline size_t lds_bytes(const LaunchShape &L, uint32_t n_nodes) {
+    return L.lds_nodes ? (size_t)n_nodes * 32 + (size_t)L.slots * 1024 * sizeof(uint16_t)
+                       : (size_t)L.slots * kBlock * sizeof(uint32_t);
+}
 
-hipError_t launch_intersect(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+#define RT_LAUNCH(kernel, blocks, threads, ...)                                                        \
+    do {                                                                                               \
+        hipError_t e_ = allow_lds(kernel, lds);                                                        \
+        if (e_ != hipSuccess) return e_;                                                               \
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, __VA_ARGS__);             \
+    } while (0)
+
+hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n,
                             rt_hit *hits, unsigned long long *counters, hipStream_t stream) {
-    uint32_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > grid) blocks = grid;
+    const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
+    uint32_t blocks = (n + threads - 1) / threads;
+    if (blocks > L.grid) blocks = L.grid;
     if (blocks == 0) return hipSuccess;
-    if (counters)
-        hipLaunchKernelGGL(k_intersect<true>, dim3(blocks), dim3(kBlock), stack_bytes(slots), stream, S, rays,
-                           n, hits, counters);
-    else
-        hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), stack_bytes(slots), stream, S, rays,
-                           n, hits, counters);
+    const size_t lds = lds_bytes(L, S.n_nodes);
+    if (L.lds_nodes) {
+        if (counters) RT_LAUNCH((k_intersect<true, true>), blocks, threads, S, rays, n, hits, counters);
+        else RT_LAUNCH((k_intersect<false, true>), blocks, threads, S, rays, n, hits, counters);
+    } else {
+        if (counters) RT_LAUNCH((k_intersect<true, false>), blocks, threads, S, rays, n, hits, counters);
+        else RT_LAUNCH((k_intersect<false, false>), blocks, threads, S, rays, n, hits, counters);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_occluded(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
-                           uint8_t *out, hipStream_t stream) {
-    uint32_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > grid) blocks = grid;
+hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
+                           hipStream_t stream) {
+    const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
+    uint32_t blocks = (n + threads - 1) / threads;
+    if (blocks > L.grid) blocks = L.grid;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_occluded, dim3(blocks), dim3(kBlock), stack_bytes(slots), stream, S, rays, n, out);
+    const size_t lds = lds_bytes(L, S.n_nodes);
+    if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out);
+    else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out);
     return hipGetLastError();
 }
 
@@ -594,15 +675,26 @@ hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue 
     return hipGetLastError();
 }
 
-hipError_t launch_bounce(const SceneDev &S, uint32_t slots, uint32_t grid, const Queue &qin, const Queue &qout,
+hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
                          unsigned long long *counters, hipStream_t stream) {
-    if (counters)
-        hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, qin, qout,
-                           counts, bounce, last, seed, radiance, counters);
-    else
-        hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), stack_bytes(slots), stream, S, qin, qout,
-                           counts, bounce, last, seed, radiance, counters);
+    const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
+    const size_t lds = lds_bytes(L, S.n_nodes);
+    if (L.lds_nodes) {
+        if (counters)
+            RT_LAUNCH((k_bounce<true, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
+                      counters);
+        else
+            RT_LAUNCH((k_bounce<false, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
+                      counters);
+    } else {
+        if (counters)
+            RT_LAUNCH((k_bounce<true, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
+                      counters);
+        else
+            RT_LAUNCH((k_bounce<false, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
+                      counters);
+    }
     return hipGetLastError();
 }
 

@@ -34,15 +34,22 @@ struct FrameDev {
     uint64_t seed;
 };
 
-hipError_t launch_intersect(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
+// How the trace kernels are launched for one scene on one device.
+struct LaunchShape {
+    uint32_t slots;  // traversal stack entries per lane
+    uint32_t grid;   // persistent workgroups
+    bool lds_nodes;  // node array staged in LDS (1024-thread workgroups), else 256-thread workgroups
+};
+
+hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n,
                             rt_hit *hits, unsigned long long *counters, hipStream_t stream);
-hipError_t launch_occluded(const SceneDev &S, uint32_t slots, uint32_t grid, const rt_ray *rays, uint32_t n,
-                           uint8_t *out, hipStream_t stream);
+hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
+                           hipStream_t stream);
 hipError_t launch_generate_rays(const rt_camera &cam, uint32_t width, uint32_t spp, uint64_t seed,
                                 uint64_t first, uint32_t n, rt_ray *rays, hipStream_t stream);
 hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
                            uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream);
-hipError_t launch_bounce(const SceneDev &S, uint32_t slots, uint32_t grid, const Queue &qin, const Queue &qout,
+hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
                          unsigned long long *counters, hipStream_t stream);
 hipError_t launch_resolve(const FrameDev &F, const float4 *radiance, uint32_t n_ranks, uint32_t s_count,
