@@ -26,6 +26,11 @@ constexpr int kBlock = 256;
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4
 #endif
+// lanes holding a leaf that trigger a leaf round (64 = wait for every lane)
+#ifndef RT_LEAF_LANES
+#define RT_LEAF_LANES 24
+#endif
+constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
 #ifndef RT_BOUNCE_WAVES
 #define RT_BOUNCE_WAVES 4
 #endif
@@ -110,57 +115,71 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
     v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
     bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
     uint32_t sp = 0, cur = S.n_nodes ? 0u : kNone, best = RT_MISS;
+    uint32_t leaf_off = 0, leaf_cnt = 0;
     for (;;) {
-        uint32_t leaf_off = 0, leaf_cnt = 0;
-        while (cur != kNone) { // interior steps, bvh.rs:760-762,778-795
-            float4 n0, n1;
-            if constexpr (LDSN) {
-                n0 = tv.lo[cur];
-                n1 = tv.hi[cur];
-            } else {
-                n0 = S.nodes[2 * (size_t)cur];
-                n1 = S.nodes[2 * (size_t)cur + 1];
-            }
-            if (COUNT) cnt.nodes++;
-            if (slab(n0, n1, ray, inv, negx, negy, negz)) {
-                uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
-                uint32_t count = meta & 0xffffu;
-                if (count > 0) {
-                    leaf_off = off;
-                    leaf_cnt = count;
-                    break;
+        // interior steps, bvh.rs:760-762,778-795: lanes that hold a leaf wait here until
+        // kLeafLanes of them do (or nobody can step any more)
+        for (;;) {
+            const bool stepping = cur != kNone && leaf_cnt == 0;
+            if (__ballot(stepping) == 0) break;
+            if ((uint32_t)__popcll(__ballot(leaf_cnt != 0)) >= kLeafLanes) break;
+            if (stepping) {
+                float4 n0, n1;
+                if constexpr (LDSN) {
+                    n0 = tv.lo[cur];
+                    n1 = tv.hi[cur];
+                } else {
+                    n0 = S.nodes[2 * (size_t)cur];
+                    n1 = S.nodes[2 * (size_t)cur + 1];
                 }
-                uint32_t axis = meta >> 16;
-                bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                stack[sp * kStride] = neg ? cur + 1 : off; // far child
-                sp++;
-                cur = neg ? off : cur + 1;
-            } else if (sp == 0) {
+                if (COUNT) cnt.nodes++;
+                if (slab(n0, n1, ray, inv, negx, negy, negz)) {
+                    uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
+                    uint32_t count = meta & 0xffffu;
+                    if (count > 0) {
+                        leaf_off = off;
+                        leaf_cnt = count;
+                    } else {
+                        uint32_t axis = meta >> 16;
+                        bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
+                        stack[sp * kStride] = neg ? cur + 1 : off; // far child
+                        sp++;
+                        cur = neg ? off : cur + 1;
+                    }
+                } else if (sp == 0) {
+                    cur = kNone;
+                } else {
+                    sp--;
+                    cur = stack[sp * kStride];
+                }
+            }
+        }
+        if (__ballot(leaf_cnt != 0) == 0) break; // every ray of the wave ran out of nodes
+        if (leaf_cnt != 0) { // leaf, bvh.rs:763-776
+            bool stop = false;
+            for (uint32_t i = 0; i < leaf_cnt; i++) {
+                LeafPrim lp = S.leaf[leaf_off + i];
+                float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                if (COUNT) {
+                    uint32_t k = lp.kind & 7u;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
+                }
+                if (prim_test(S, lp, ray, t, b0, b1, b2)) {
+                    ray.t_max = t;
+                    best = leaf_off + i;
+                    a0 = b0; a1 = b1; a2 = b2;
+                    if (ANY) { stop = true; break; }
+                }
+            }
+            leaf_cnt = 0;
+            if (stop || sp == 0) {
                 cur = kNone;
             } else {
                 sp--;
                 cur = stack[sp * kStride];
             }
         }
-        if (leaf_cnt == 0) break; // no node left for this ray
-        for (uint32_t i = 0; i < leaf_cnt; i++) { // leaf, bvh.rs:763-771
-            LeafPrim lp = S.leaf[leaf_off + i];
-            float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-            if (COUNT) {
-                uint32_t k = lp.kind & 7u;
-#pragma unroll
-                for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
-            }
-            if (prim_test(S, lp, ray, t, b0, b1, b2)) {
-                if (ANY) return leaf_off + i;
-                ray.t_max = t;
-                best = leaf_off + i;
-                a0 = b0; a1 = b1; a2 = b2;
-            }
-        }
-        if (sp == 0) break; // bvh.rs:772-776
-        sp--;
-        cur = stack[sp * kStride];
     }
     return best;
 }

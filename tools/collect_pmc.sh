@@ -1,10 +1,10 @@
 #!/bin/bash
 # Hardware-counter passes for the bench workload (run on the GPU box through gpurun).
 # One rocprofv3 process per pass; counters never combined with tracing options.
-# usage: tools/collect_pmc.sh <outdir> [bench args...]
+# usage: tools/collect_pmc.sh <outdir> [script.py args...]   (default: bench.py at 8 spp)
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:---spp 8 --steps 1 --warmup 0 --no-cpu-baseline}
+ARGS=${@:-bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -18,7 +18,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout -s KILL 170 rocprofv3 --pmc $P --output-format csv -d "$ROOT/$OUT/pass$i" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/pass$i.log" 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc $P --output-format csv -d "$ROOT/$OUT/pass$i" -- python3 $ROOT/$ARGS > "$ROOT/$OUT/pass$i.log" 2>&1
   rc=$?
   echo "pass $i rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 "$ROOT/$OUT/pass$i.log"; exit $rc; fi
