@@ -78,10 +78,9 @@ def main():
     import torch.distributed as dist
 
     from raytracer_amd import abi, lib, scenes
+    from raytracer_amd.distributed import env_rank, render_frame
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
@@ -101,11 +100,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def frame(flags=0):
-        opts = lib.render_opts(WIDTH, HEIGHT, args.spp, DEPTH, seed=0, shard=(rank, world), flags=flags)
-        st = scene.render_dev(cam, opts, fb.data_ptr(), stream)
-        if world > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
-        return st
+        def shard(index, count, buf):
+            opts = lib.render_opts(WIDTH, HEIGHT, args.spp, DEPTH, seed=0, shard=(index, count), flags=flags)
+            return scene.render_dev(cam, opts, buf.data_ptr(), stream)
+
+        return render_frame(shard, fb, rank, world, dist)
 
     def fence():
         if world > 1:

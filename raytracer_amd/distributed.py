@@ -1,0 +1,32 @@
+"""Multi-GPU frame rendering: one process per GPU, tiles dealt round-robin.
+
+The scene is replicated on every rank.  Rank r of N renders the 32x32 tiles t
+with t % N == r into a zeroed full-size framebuffer (``render_shard``), and one
+``reduce(sum)`` to rank 0 assembles the frame -- the only collective of the
+path.  Tiles are disjoint, so the sum adds each pixel to zeros and the result
+is bit-identical to a single-GPU frame.
+"""
+import os
+
+
+def env_rank():
+    """(rank, world_size, local_rank) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def tiles_of(width, height, rank, world):
+    """Indices of the 32x32 tiles (row-major) that ``rank`` owns."""
+    tiles_x, tiles_y = (width + 31) // 32, (height + 31) // 32
+    return list(range(rank, tiles_x * tiles_y, world))
+
+
+def render_frame(render_shard, framebuffer, rank, world, dist=None):
+    """``render_shard(shard_index, shard_count, framebuffer)`` fills this rank's
+    tiles (and zeroes the rest); with world > 1 the buffers are summed onto
+    rank 0 through ``dist`` (torch.distributed, backend nccl = RCCL on GPUs,
+    gloo in CPU tests).  Returns what ``render_shard`` returned."""
+    out = render_shard(rank, world, framebuffer)
+    if world > 1:
+        dist.reduce(framebuffer, dst=0, op=dist.ReduceOp.SUM)
+    return out

@@ -1,0 +1,150 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every
+symbol include/rt355.h declares, struct layouts match the ctypes mirror, the host
+BVH builder produces the oracle's tree bit for bit, argument errors come back as
+codes (never aborts), and compute entry points refuse to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, lib
+from raytracer_amd.scene import SceneData
+from tests import orc
+from tests.mixed import mixed_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    header = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(abi.EXPORTS), declared ^ set(abi.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_layouts_match():
+    L = lib.load()
+    out = (C.c_uint32 * 64)()
+    n = L.rt_abi_sizes(out, 64)
+    assert n == len(abi.ABI_SIZES)
+    for (name, size), got in zip(abi.ABI_SIZES, out[:n]):
+        assert size == got, (name, size, got)
+
+
+@pytest.mark.parametrize("split", range(4))
+@pytest.mark.parametrize("max_prims", [1, 4, 255, 1000])
+def test_builder_matches_oracle_bit_for_bit(split, max_prims):
+    fr = mixed_scene(seed=40 + split, n_each=80).freeze()
+    g, o = lib.Scene(fr, max_prims, split), orc.OracleScene(fr, max_prims, split)
+    assert g.nodes().tobytes() == o.nodes().tobytes()
+    assert (g.prim_order() == o.prim_order()).all()
+    assert (g.world_bound() == o.world_bound()).all()
+    gi, oi = g.info(), o.info()
+    assert (gi.n_prims, gi.n_nodes, gi.max_depth) == (oi.n_prims, oi.n_nodes, oi.max_depth)
+    # max_prims_in_node is clamped to 255 (bvh.rs:114)
+    assert g.nodes()["primitive_count"].max() <= 255 or split != abi.RT_SPLIT_HLBVH
+
+
+@pytest.mark.parametrize("name", ["random", "cornell", "week", "pbrt"])
+def test_named_scene_trees_match_oracle(scene_cache, name):
+    fr = scene_cache(name)[2]
+    for split in range(4):
+        g, o = lib.Scene(fr, 4, split), orc.OracleScene(fr, 4, split)
+        assert g.nodes().tobytes() == o.nodes().tobytes(), (name, split)
+        assert (g.prim_order() == o.prim_order()).all()
+
+
+def test_large_build_matches_oracle():
+    s = SceneData()
+    s.lambertian((1, 1, 1))
+    rng = np.random.default_rng(3)
+    s.add_sphere_block(rng.random((60000, 3)) * 100, rng.random(60000) * 0.3 + 0.05)
+    tri = rng.random((40000, 1, 3)) * 100 + (rng.random((40000, 3, 3)) - 0.5)
+    s.add_triangles(tri)
+    fr = s.freeze()
+    for split in (abi.RT_SPLIT_SAH, abi.RT_SPLIT_HLBVH):
+        g, o = lib.Scene(fr, 4, split), orc.OracleScene(fr, 4, split)
+        assert g.nodes().tobytes() == o.nodes().tobytes()
+        assert (g.prim_order() == o.prim_order()).all()
+        assert g.info().max_depth <= 64
+
+
+def test_errors_are_codes_not_aborts():
+    L = lib.load()
+    h = C.c_void_p()
+    opts = abi.rt_build_opts(4, 0)
+    assert L.rt_scene_create(None, C.byref(opts), C.byref(h)) == abi.RT_ERR_INVALID
+    assert b"null" in L.rt_last_error()
+    # primitive index out of range
+    s = SceneData()
+    s.lambertian((1, 1, 1))
+    s.add_sphere((0, 0, 0), 1.0)
+    fr = s.freeze()
+    fr.desc.n_spheres = 0
+    assert L.rt_scene_create(C.byref(fr.desc), C.byref(opts), C.byref(h)) == abi.RT_ERR_INVALID
+    assert b"malformed" in L.rt_last_error()
+    with pytest.raises(lib.RtError):
+        lib.Scene(fr)
+    # unknown primitive kind, bad material, bad texture reference
+    for mutate in ("kind", "material", "texture"):
+        s = SceneData()
+        s.lambertian((1, 1, 1))
+        s.add_sphere((0, 0, 0), 1.0)
+        fr = s.freeze()
+        if mutate == "kind":
+            fr._keep["prims"]["kind"][0] = 99
+        elif mutate == "material":
+            fr._keep["prims"]["material"][0] = 5
+        else:
+            fr._keep["materials"]["texture"][0] = 7
+        assert L.rt_scene_create(C.byref(fr.desc), C.byref(opts), C.byref(h)) == abi.RT_ERR_INVALID, mutate
+        assert orc.lib().orc_scene_create(C.byref(fr.desc), C.byref(opts), C.byref(h)) == abi.RT_ERR_INVALID
+    assert L.rt_scene_world_bound(None, None) == abi.RT_ERR_INVALID
+    L.rt_scene_destroy(None)  # no-op
+
+
+def test_deep_tree_is_rejected_like_the_reference_stack():
+    # centroids spaced geometrically make the middle split peel one primitive per level:
+    # the tree needs more than the 64 stack entries of bvh.rs:753
+    s = SceneData()
+    s.lambertian((1, 1, 1))
+    for k in range(80):
+        c = 4.0 ** (k - 40)
+        s.add_sphere((c, 0.0, 0.0), 0.1 * c)
+    fr = s.freeze()
+    with pytest.raises(lib.RtError) as e:
+        lib.Scene(fr, 1, abi.RT_SPLIT_MIDDLE)
+    assert e.value.code == abi.RT_ERR_DEPTH
+    with pytest.raises(orc.OracleError):
+        orc.OracleScene(fr, 1, abi.RT_SPLIT_MIDDLE)
+    assert lib.Scene(fr, 1, abi.RT_SPLIT_EQUAL_COUNTS).info().max_depth <= 9
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    s = SceneData()
+    s.lambertian((1, 1, 1))
+    s.add_sphere((0, 0, 0), 1.0)
+    g = lib.Scene(s.freeze())
+    rays = np.zeros(4, dtype=abi.ray_dtype)
+    for call in (lambda: g.intersect(rays), lambda: g.does_intersect(rays), lambda: g.upload()):
+        with pytest.raises(lib.RtError) as e:
+            call()
+        assert e.value.code == abi.RT_ERR_NO_DEVICE and "no CPU path" in str(e.value)
+    # a negative device index is an error as well, never a CPU fallback
+    g.device = -1
+    with pytest.raises(lib.RtError):
+        g.intersect(rays)
+
+
+def test_missing_library_is_an_import_error(monkeypatch):
+    monkeypatch.setattr(lib, "_LIB", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/librt355.so")
+    with pytest.raises(ImportError):
+        lib.load()
