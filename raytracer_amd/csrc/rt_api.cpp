@@ -287,9 +287,12 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         const uint32_t id = s.tree.order[k];
         const rt_prim_ref &pr = s.prims[id];
         const uint32_t kind = pr.kind & 0xffu;
-        rt::LeafPrim lp{(pr.kind & 0x1ffu) | (pr.xform << 16), 0, id, pr.material};
+        rt::LeafPrim lp{(pr.kind & 0x1ffu) | (pr.xform << 16), 0, id, pr.material, make_float4(0, 0, 0, 0)};
         switch (kind) {
-        case RT_SPHERE: lp.index = push_sphere(pr.index); break;
+        case RT_SPHERE:
+            lp.index = push_sphere(pr.index);
+            lp.geom = spheres.back();
+            break;
         case RT_MOVING_SPHERE: {
             const rt_moving_sphere &m = s.moving[pr.index];
             rt::MSphere o{};
@@ -328,8 +331,12 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         default: { // RT_MEDIUM
             const rt_medium &m = s.media[pr.index];
             rt::Medium o{m.boundary_kind, 0, m.xform, m.density};
-            o.boundary_index = m.boundary_kind == RT_BOUNDARY_SPHERE ? push_sphere(m.boundary_index)
-                                                                     : push_box(m.boundary_index);
+            if (m.boundary_kind == RT_BOUNDARY_SPHERE) {
+                o.boundary_index = push_sphere(m.boundary_index);
+                lp.geom = spheres.back();
+            } else {
+                o.boundary_index = push_box(m.boundary_index);
+            }
             media.push_back(o);
             lp.index = (uint32_t)media.size() - 1;
             break;

@@ -20,6 +20,7 @@ struct LeafPrim {      // one entry per primitive, in leaf order (BVH::primitive
     uint32_t index;    // index into the typed table (tables are packed in leaf order)
     uint32_t prim;     // caller's primitive index
     uint32_t material;
+    float4 geom;       // sphere: {c.xyz, r}; medium in a sphere: its boundary {c.xyz, r}; else unused
 };
 
 struct GSphere { // derived form of rt_gsphere, 128 B
@@ -435,11 +436,11 @@ RT_DEV float medium_uniform(const Ray &ray, uint32_t prim) {
     h = hash32(prim ^ h);
     return (float)(h >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
-RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, const Ray &ray, float &t_out) {
+RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float4 sp, const Ray &ray,
+                        float &t_out) {
     float t_in, t_out_b;
     v3 o, d;
     if (m.boundary_kind == RT_BOUNDARY_SPHERE) {
-        float4 sp = S.spheres[m.boundary_index];
         o = ray.o - mk(sp.x, sp.y, sp.z);
         d = ray.d;
         if (!sphere_roots(o, d, sp.w, t_in, t_out_b)) return false;
@@ -470,7 +471,7 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, flo
     float t0, t1;
     switch (kind) {
     case RT_SPHERE: {
-        float4 sp = S.spheres[lp.index];
+        float4 sp = lp.geom;
         if (!sphere_roots(ray.o - mk(sp.x, sp.y, sp.z), ray.d, sp.w, t0, t1)) return false;
         return sphere_pick(t0, t1, ray.t_max, t);
     }
@@ -513,7 +514,7 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, flo
         return true;
     }
     case RT_GSPHERE: return gsphere_test(S.gsph[lp.index], ray, t);
-    case RT_MEDIUM: return medium_test(S, lp.prim, S.media[lp.index], ray, t);
+    case RT_MEDIUM: return medium_test(S, lp.prim, S.media[lp.index], lp.geom, ray, t);
     default: return false;
     }
 }
@@ -561,7 +562,7 @@ RT_DEV void prim_finalize(const SceneDev &S, const LeafPrim &lp, const Ray &ray,
     out.v = 0.0f;
     switch (kind) {
     case RT_SPHERE: {
-        float4 sp = S.spheres[lp.index];
+        float4 sp = lp.geom;
         v3 c = mk(sp.x, sp.y, sp.z);
         sphere_surface(ray.o - c, ray.d, c, sp.w, t, out);
         break;
