@@ -54,7 +54,7 @@ def cpu_baseline(frozen, cam, threads, target_s=15.0):
     t0 = time.time()
     _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, 1, DEPTH, seed=0), threads=threads)
     t1 = time.time() - t0
-    spp = max(1, min(16, int(target_s / max(t1, 1e-3))))
+    spp = max(1, min(SPP, int(target_s / max(t1, 1e-3))))
     t0 = time.time()
     _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, spp, DEPTH, seed=0), threads=threads)
     dt = time.time() - t0

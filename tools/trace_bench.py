@@ -85,6 +85,15 @@ def main():
                       "prims_per_ray": round(float(cnt[1:].sum()) / m, 2)}
     ms = timed(lambda: scene.occluded_dev(b_rays.data_ptr(), m, d_occ.data_ptr(), stream))
     out["bounce1_any_hit"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+    # host-pointer entry points: PCIe staging included (rays up, hits down)
+    import time
+    h_rays = b_rays[:1 << 22].cpu().numpy().view(abi.ray_dtype).reshape(-1)
+    scene.intersect(h_rays)
+    t0 = time.perf_counter()
+    scene.intersect(h_rays)
+    dt = time.perf_counter() - t0
+    out["bounce1_host_pointers"] = {"rays": len(h_rays), "ms": round(dt * 1e3, 3),
+                                    "Mrays_s": round(len(h_rays) / dt / 1e6, 1)}
     print(json.dumps(out))
 
 
