@@ -218,7 +218,7 @@ typedef struct rt_scene_info {
     uint32_t n_prims;
     uint32_t n_nodes;
     uint32_t max_depth;   /* maximum number of simultaneously stacked nodes + 1   */
-    uint32_t stack_slots; /* LDS stack entries per lane the kernels will use      */
+    uint32_t stack_slots; /* stack entries a lane of the kernels can need (max_depth - 1) */
     uint64_t device_bytes;
     double build_ms;
 } rt_scene_info;

@@ -250,21 +250,36 @@ void release(DeviceBuffers &db) {
     db.ws_allocs.clear();
 }
 
-// Lays the scene out for the kernels: nodes as two float4 per node, the
-// primitive list in leaf order, and every typed table re-packed in the order
-// the leaves reference it so that a leaf's primitives sit next to each other.
+// Lays the scene out for the kernels: one 64-byte record per interior node with
+// the boxes of both children, the primitive list in leaf order, and every typed
+// table re-packed in the order the leaves reference it so that a leaf's
+// primitives sit next to each other.
 int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     HIP_TRY(hipSetDevice(device));
     const auto &nodes = s.tree.nodes;
-    std::vector<float4> dn(2 * nodes.size());
+    // records are numbered in the pre-order of the flattened tree (bvh.rs:661-691)
+    std::vector<uint32_t> record_of(nodes.size(), 0);
+    uint32_t n_pairs = 0;
+    for (size_t i = 0; i < nodes.size(); i++)
+        if (nodes[i].primitive_count == 0) record_of[i] = n_pairs++;
+    auto ref_of = [&](size_t i) {
+        return nodes[i].primitive_count ? (rt::kLeafRef | nodes[i].child_offset) : record_of[i];
+    };
+    auto bits = [](uint32_t v) {
+        float f;
+        memcpy(&f, &v, 4);
+        return f;
+    };
+    std::vector<float4> dn(4 * (size_t)n_pairs);
     for (size_t i = 0; i < nodes.size(); i++) {
         const rt_linear_node &n = nodes[i];
-        uint32_t meta = (uint32_t)n.primitive_count | ((uint32_t)n.axis << 16);
-        float w0, w1;
-        memcpy(&w0, &n.child_offset, 4);
-        memcpy(&w1, &meta, 4);
-        dn[2 * i] = make_float4(n.lo[0], n.lo[1], n.lo[2], w0);
-        dn[2 * i + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], w1);
+        if (n.primitive_count) continue;
+        const rt_linear_node &c0 = nodes[i + 1], &c1 = nodes[n.child_offset];
+        float4 *r = dn.data() + 4 * (size_t)record_of[i];
+        r[0] = make_float4(c0.lo[0], c0.lo[1], c0.lo[2], bits(ref_of(i + 1)));
+        r[1] = make_float4(c0.hi[0], c0.hi[1], c0.hi[2], bits(ref_of(n.child_offset)));
+        r[2] = make_float4(c1.lo[0], c1.lo[1], c1.lo[2], bits(n.axis));
+        r[3] = make_float4(c1.hi[0], c1.hi[1], c1.hi[2], 0.0f);
     }
     std::vector<rt::LeafPrim> leaf(s.prims.size());
     std::vector<float4> spheres, tris;
@@ -344,6 +359,8 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         }
         leaf[k] = lp;
     }
+    for (const rt_linear_node &n : nodes)
+        if (n.primitive_count) leaf[n.child_offset + n.primitive_count - 1].kind |= rt::kLastInLeaf;
     rt::SceneDev &D = db.dev;
     int rc;
     if ((rc = upload(db, dn, &D.nodes))) return rc;
@@ -371,6 +388,12 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     if ((rc = upload(db, imgs, &D.images))) return rc;
     D.n_nodes = (uint32_t)nodes.size();
     D.n_prims = (uint32_t)leaf.size();
+    D.n_pairs = n_pairs;
+    D.root_ref = nodes.empty() ? 0u : ref_of(0);
+    for (int c = 0; c < 3; c++) {
+        D.root_lo[c] = nodes.empty() ? 0.0f : nodes[0].lo[c];
+        D.root_hi[c] = nodes.empty() ? 0.0f : nodes[0].hi[c];
+    }
     memcpy(D.background, s.background, sizeof D.background);
 
     void *p = nullptr;
@@ -380,22 +403,33 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    // Persistent grid.  If the node array and 16-bit stacks of a 1024-thread workgroup fit in
-    // one CU's LDS the tree is traversed from LDS (one workgroup per CU); otherwise 256-thread
-    // workgroups with 32-bit stacks, as many per CU as the stacks allow.
-    const uint32_t slots = s.tree.max_depth ? s.tree.max_depth : 1;
-    const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor;
-    const size_t lds_tree = nodes.size() * 32 + (size_t)slots * 1024 * sizeof(uint16_t);
-    const char *force = getenv("RT355_NODES"); // "global" or "lds": override for experiments
-    bool lds_nodes = !nodes.empty() && nodes.size() < 65536 && lds_tree <= lds_cu &&
-                     lds_tree <= (size_t)prop.sharedMemPerBlockOptin;
+    // Persistent grid.  A lane stacks at most one far child per interior level, i.e.
+    // max_depth - 1 entries; the first stack_lds of them live in LDS, the rest in private
+    // memory.  If the records and at least kMinLds stack levels of a 1024-thread workgroup
+    // fit in one CU's LDS the tree is traversed from LDS (one workgroup per CU, 16-bit
+    // references); otherwise 256-thread workgroups read records from global memory, with
+    // as many stack levels in LDS as still leave room for four workgroups per CU.
+    const uint32_t slots = s.tree.max_depth > 1 ? s.tree.max_depth - 1 : 1;
+    const size_t lds_cu = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlockOptin);
+    constexpr uint32_t kMinLds = 8;
+    const char *force = getenv("RT355_NODES"); // "global": override for experiments
+    bool lds_nodes = false;
+    uint32_t stack_lds = 0;
+    if (n_pairs > 0 && n_pairs < 0x8000u && leaf.size() < 0x8000u && (size_t)n_pairs * 64 < lds_cu) {
+        const size_t room = lds_cu - (size_t)n_pairs * 64;
+        stack_lds = (uint32_t)std::min<size_t>(slots, room / (1024 * 6));
+        lds_nodes = stack_lds >= std::min(slots, kMinLds);
+    }
     if (force && !strcmp(force, "global")) lds_nodes = false;
+    if (!lds_nodes) stack_lds = (uint32_t)std::min<size_t>(slots, lds_cu / 4 / (256 * 8));
+    if (slots - stack_lds > rt::kSpillLevels) return fail(RT_ERR_LIMIT, "traversal stack too deep for this device");
+    D.stack_lds = stack_lds;
     db.shape.slots = slots;
     db.shape.lds_nodes = lds_nodes;
     if (lds_nodes) {
         db.shape.grid = (uint32_t)prop.multiProcessorCount;
     } else {
-        size_t lds = (size_t)slots * 256 * 4;
+        size_t lds = rt::lds_bytes(false, n_pairs, stack_lds);
         uint32_t per_cu = (uint32_t)(lds_cu / (lds ? lds : 1));
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
@@ -428,7 +462,7 @@ int get_device(rt_scene *s, int device, DeviceBuffers **out) {
     return RT_OK;
 }
 
-uint32_t stack_slots(const rt_scene *s) { return s->tree.max_depth ? s->tree.max_depth : 1; }
+uint32_t stack_slots(const rt_scene *s) { return s->tree.max_depth > 1 ? s->tree.max_depth - 1 : 1; }
 
 constexpr size_t kChunk = 1u << 28; // rays per launch (32-bit indices in the kernels)
 

@@ -16,12 +16,15 @@ namespace rt {
 
 // ---- resident scene (device pointers), passed to kernels by value --------------
 struct LeafPrim {      // one entry per primitive, in leaf order (BVH::primitives, bvh.rs:35)
-    uint32_t kind;     // rt_prim_kind | reverse << 8 | xform << 16
+    uint32_t kind;     // rt_prim_kind | reverse << 8 | last-of-its-leaf << 9 | xform << 16
     uint32_t index;    // index into the typed table (tables are packed in leaf order)
     uint32_t prim;     // caller's primitive index
     uint32_t material;
     float4 geom;       // sphere: {c.xyz, r}; medium in a sphere: its boundary {c.xyz, r}; else unused
 };
+
+constexpr uint32_t kLastInLeaf = 0x200u; // LeafPrim.kind: no further primitive in this leaf
+constexpr uint32_t kLeafRef = 0x80000000u; // child reference: leaf starting at primitive (ref & ~kLeafRef)
 
 struct GSphere { // derived form of rt_gsphere, 128 B
     float o2w[12];
@@ -45,7 +48,11 @@ struct ImageDev {
 };
 
 struct SceneDev {
-    const float4 *nodes;      // 2 x float4 per node: {lo.xyz, child_offset} {hi.xyz, count | axis << 16}
+    // One 64-byte record per interior node holding the boxes of both children
+    // (LinearBVHNode.bounds of node + 1 and of node child_offset, bvh.rs:83-89):
+    //   {lo0.xyz, ref0} {hi0.xyz, ref1} {lo1.xyz, split axis} {hi1.xyz, -}
+    // refN = index of the child's own record, or kLeafRef | first primitive of a leaf child.
+    const float4 *nodes;
     const LeafPrim *leaf;     // n_prims
     const float4 *spheres;    // {c.xyz, r}
     const MSphere *msph;
@@ -62,7 +69,11 @@ struct SceneDev {
     const ImageDev *images;
     const float *perlin_vec;
     const int32_t *perlin_perm;
-    uint32_t n_nodes, n_prims;
+    uint32_t n_nodes, n_prims; // n_nodes: LinearBVHNode count of the tree (0 = empty scene)
+    uint32_t n_pairs;          // interior records in `nodes`
+    uint32_t root_ref;         // reference to the root (a leaf when the tree is a single node)
+    uint32_t stack_lds;        // stack levels per lane kept in LDS; deeper entries use private memory
+    float root_lo[3], root_hi[3];
     float background[3];
 };
 
@@ -679,7 +690,11 @@ RT_DEV void prim_finalize(const SceneDev &S, const LeafPrim &lp, const Ray &ray,
 }
 
 // ---- slab test, geometry/src/bounds3.rs:212-238 ------------------------------------------
-RT_DEV bool slab(float4 n0, float4 n1, const Ray &ray, v3 inv, bool negx, bool negy, bool negz) {
+// Bounds3::intersect_inv, geometry/src/bounds3.rs:212-238.  t_near is the entry
+// distance the final comparison `t_near < ray.t_max` used: the only term of the
+// test that depends on ray.t_max, so a caller that keeps it can repeat the test
+// against a shortened ray without the box.
+RT_DEV bool slab(float4 n0, float4 n1, const Ray &ray, v3 inv, bool negx, bool negy, bool negz, float &t_near) {
     const float g = 1.0f + 2.0f * G3;
     float t_min = ((negx ? n1.x : n0.x) - ray.o.x) * inv.x;
     float t_max = ((negx ? n0.x : n1.x) - ray.o.x) * inv.x;
@@ -696,6 +711,7 @@ RT_DEV bool slab(float4 n0, float4 n1, const Ray &ray, v3 inv, bool negx, bool n
     if (t_min > tz_max || tz_min > t_max) return false;
     t_min = sel_max(t_min, tz_min);
     t_max = sel_min(t_max, tz_max);
+    t_near = t_min;
     return t_min < ray.t_max && t_max > 0.0f;
 }
 

@@ -42,53 +42,66 @@ RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
 RT_DEV uint32_t wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
 RT_DEV uint32_t wave_total() { return gridDim.x * (blockDim.x >> 6); }
 
-// Two launch shapes.  Trees whose nodes fit beside the stacks are copied into
-// LDS by every workgroup (1024 threads, one per CU): incoherent rays then fetch
-// nodes with ds_read_b128 from two separate arrays (lower corner + offset /
-// upper corner + count, so that 16 lanes spread over all 16-byte slots of a
-// bank row) instead of queueing 64 distinct cache lines per load in the vector
-// L1.  Larger trees stay in global memory (256-thread workgroups).
+// Two launch shapes.  Trees whose interior records fit beside the stacks are
+// copied into LDS by every workgroup (1024 threads, one per CU): incoherent rays
+// then fetch nodes with ds_read_b128 from four separate arrays (one per 16-byte
+// quarter of the record, so that the lanes of one read spread over all 16-byte
+// slots of a bank row) instead of queueing 64 distinct cache lines per load in
+// the vector L1.  Larger trees stay in global memory (256-thread workgroups, one
+// 64-byte line per record).
 template <bool LDSN>
 struct Shape;
 template <>
 struct Shape<false> {
     static constexpr int kThreads = kBlock;
     static constexpr int kWaves = RT_TRACE_WAVES;
-    using StackT = uint32_t;
+    using RefT = uint32_t;
 };
 template <>
 struct Shape<true> {
     static constexpr int kThreads = 1024;
     static constexpr int kWaves = 4;
-    using StackT = uint16_t;
+    using RefT = uint16_t; // record index < 2^15, or 0x8000 | first primitive of a leaf
 };
+
+// Stack entries beyond the LDS part live in a per-lane private array.
+constexpr int kSpill = (int)kSpillLevels;
 
 extern __shared__ float4 lds_raw[];
 
 template <bool LDSN>
 struct TreeView {
-    const float4 *lo, *hi; // LDS copies (LDSN) or unused
-    typename Shape<LDSN>::StackT *stack;
+    const float4 *q;     // LDSN: LDS copy, quarter k of record i at q[k * n_pairs + i]
+    uint32_t n_pairs;
+    typename Shape<LDSN>::RefT *ref; // stack part in LDS: ref[level * kThreads], near[level * kThreads]
+    float *near;
+    uint32_t levels;     // stack levels kept in LDS
 };
 
-// Carves the dynamic LDS; with LDSN also stages the node array (call from all threads).
+// Carves the dynamic LDS; with LDSN also stages the records (call from all threads).
 template <bool LDSN>
 RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
+    constexpr int kThreads = Shape<LDSN>::kThreads;
     TreeView<LDSN> v;
+    v.n_pairs = S.n_pairs;
+    v.levels = S.stack_lds;
+    float4 *base = lds_raw;
     if constexpr (LDSN) {
-        float4 *lo = lds_raw, *hi = lds_raw + S.n_nodes;
-        for (uint32_t i = threadIdx.x; i < S.n_nodes; i += Shape<true>::kThreads) {
-            lo[i] = S.nodes[2 * (size_t)i];
-            hi[i] = S.nodes[2 * (size_t)i + 1];
+        const uint32_t n = S.n_pairs;
+        for (uint32_t i = threadIdx.x; i < 4 * n; i += kThreads) {
+            float4 x = S.nodes[i]; // record i / 4, quarter i % 4
+            base[(i & 3u) * n + (i >> 2)] = x;
         }
         __syncthreads();
-        v.lo = lo;
-        v.hi = hi;
-        v.stack = reinterpret_cast<uint16_t *>(lds_raw + 2 * (size_t)S.n_nodes) + threadIdx.x;
+        v.q = base;
+        base += 4 * (size_t)n;
     } else {
-        v.lo = v.hi = nullptr;
-        v.stack = reinterpret_cast<uint32_t *>(lds_raw) + threadIdx.x;
+        v.q = nullptr;
     }
+    v.near = reinterpret_cast<float *>(base) + threadIdx.x;
+    v.ref = reinterpret_cast<typename Shape<LDSN>::RefT *>(reinterpret_cast<float *>(base) +
+                                                            (size_t)S.stack_lds * kThreads) +
+            threadIdx.x;
     return v;
 }
 
@@ -101,64 +114,128 @@ struct Counters {
 // shortened on every accepted hit (ties go to the primitive tested later).
 // Returns the leaf slot of the winning primitive or RT_MISS.
 //
-// Same visiting order per ray as the reference loop, scheduled for a 64-wide
-// wave: every lane first walks interior nodes until it holds a leaf (or runs
-// out of nodes), then the lanes that hold a leaf test its primitives together.
-// The primitive code (a switch over seven kinds) is therefore executed once
-// per leaf round instead of once per node step.
+// Same visiting order and the same box and primitive tests per ray as the
+// reference loop, re-associated so that one step handles an interior node's two
+// children: the reference pops a node, tests its box, and for an interior node
+// continues with the near child while the far child waits on the stack
+// (bvh.rs:778-795); both children are tested when they are popped.  Here the
+// two boxes sit in the parent's record and are tested together.  The near
+// child's test is the one the reference makes next.  The far child's test
+// depends on the ray only through `t_near < ray.t_max`, so its t_near goes on
+// the stack with it and the comparison is repeated against the ray as it is
+// when the entry is popped: exactly the outcome of the reference's later test.
+// A child whose box fails is never stacked; the reference would pop it, test
+// it and discard it, so the visit counter still counts both children.
+//
+// Scheduled for a 64-wide wave: every lane walks interior records until it
+// holds a leaf (or runs out of nodes), then the lanes that hold a leaf test its
+// primitives together, so the primitive code (a switch over seven kinds) runs
+// once per leaf round instead of once per node step.
 template <bool ANY, bool COUNT, bool LDSN>
 RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, float &a0, float &a1, float &a2,
                          Counters &cnt) {
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     constexpr int kStride = Shape<LDSN>::kThreads;
-    typename Shape<LDSN>::StackT *stack = tv.stack;
+    using RefT = typename Shape<LDSN>::RefT;
+    RefT *const s_ref = tv.ref;
+    float *const s_near = tv.near;
+    const uint32_t levels = tv.levels;
+    uint32_t spill_ref[kSpill];
+    float spill_near[kSpill];
     v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
     bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
-    uint32_t sp = 0, cur = S.n_nodes ? 0u : kNone, best = RT_MISS;
-    uint32_t leaf_off = 0, leaf_cnt = 0;
+    uint32_t sp = 0, cur = kNone, best = RT_MISS;
+
+    auto push = [&](uint32_t r, float t) {
+        if (sp < levels) {
+            if constexpr (LDSN) s_ref[sp * kStride] = (RefT)((r & 0x7fffu) | ((r >> 31) << 15));
+            else s_ref[sp * kStride] = r;
+            s_near[sp * kStride] = t;
+        } else {
+            spill_ref[sp - levels] = r;
+            spill_near[sp - levels] = t;
+        }
+        sp++;
+    };
+    // next stacked node whose box the shortened ray still enters (bvh.rs:760-762 on a popped node)
+    auto pop = [&]() {
+        uint32_t r = kNone;
+        while (sp > 0) {
+            sp--;
+            uint32_t e;
+            float t;
+            if (sp < levels) {
+                e = s_ref[sp * kStride];
+                if constexpr (LDSN) e = (e & 0x7fffu) | ((e & 0x8000u) << 16);
+                t = s_near[sp * kStride];
+            } else {
+                e = spill_ref[sp - levels];
+                t = spill_near[sp - levels];
+            }
+            if (t < ray.t_max) {
+                r = e;
+                break;
+            }
+        }
+        return r;
+    };
+
+    if (S.n_nodes) { // the root's own box, bvh.rs:757-762
+        if (COUNT) cnt.nodes++;
+        float t;
+        float4 r0 = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f);
+        float4 r1 = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
+        if (slab(r0, r1, ray, inv, negx, negy, negz, t)) cur = S.root_ref;
+    }
     for (;;) {
-        // interior steps, bvh.rs:760-762,778-795: lanes that hold a leaf wait here until
-        // kLeafLanes of them do (or nobody can step any more)
+        // interior steps: lanes that hold a leaf wait here until kLeafLanes of them do (or
+        // nobody can step any more)
         for (;;) {
-            const bool stepping = cur != kNone && leaf_cnt == 0;
+            const bool stepping = (cur >> 31) == 0;
+            const bool holding = !stepping && cur != kNone;
             if (__ballot(stepping) == 0) break;
-            if ((uint32_t)__popcll(__ballot(leaf_cnt != 0)) >= kLeafLanes) break;
+            if ((uint32_t)__popcll(__ballot(holding)) >= kLeafLanes) break;
             if (stepping) {
-                float4 n0, n1;
+                float4 q0, q1, q2, q3;
                 if constexpr (LDSN) {
-                    n0 = tv.lo[cur];
-                    n1 = tv.hi[cur];
+                    const float4 *q = tv.q + cur;
+                    const uint32_t n = tv.n_pairs;
+                    q0 = q[0];
+                    q1 = q[n];
+                    q2 = q[2 * (size_t)n];
+                    q3 = q[3 * (size_t)n];
                 } else {
-                    n0 = S.nodes[2 * (size_t)cur];
-                    n1 = S.nodes[2 * (size_t)cur + 1];
+                    const float4 *q = S.nodes + 4 * (size_t)cur;
+                    q0 = q[0];
+                    q1 = q[1];
+                    q2 = q[2];
+                    q3 = q[3];
                 }
-                if (COUNT) cnt.nodes++;
-                if (slab(n0, n1, ray, inv, negx, negy, negz)) {
-                    uint32_t off = __float_as_uint(n0.w), meta = __float_as_uint(n1.w);
-                    uint32_t count = meta & 0xffffu;
-                    if (count > 0) {
-                        leaf_off = off;
-                        leaf_cnt = count;
-                    } else {
-                        uint32_t axis = meta >> 16;
-                        bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz);
-                        stack[sp * kStride] = neg ? cur + 1 : off; // far child
-                        sp++;
-                        cur = neg ? off : cur + 1;
-                    }
-                } else if (sp == 0) {
-                    cur = kNone;
+                if (COUNT) cnt.nodes += 2;
+                float t0, t1;
+                const bool h0 = slab(q0, q1, ray, inv, negx, negy, negz, t0);
+                const bool h1 = slab(q2, q3, ray, inv, negx, negy, negz, t1);
+                const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+                const uint32_t axis = __float_as_uint(q2.w);
+                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz); // second child is nearer
+                if (h0 && h1) {
+                    push(neg ? r0 : r1, neg ? t0 : t1);
+                    cur = neg ? r1 : r0;
+                } else if (h0) {
+                    cur = r0;
+                } else if (h1) {
+                    cur = r1;
                 } else {
-                    sp--;
-                    cur = stack[sp * kStride];
+                    cur = pop();
                 }
             }
         }
-        if (__ballot(leaf_cnt != 0) == 0) break; // every ray of the wave ran out of nodes
-        if (leaf_cnt != 0) { // leaf, bvh.rs:763-776
+        const bool holding = (cur >> 31) != 0 && cur != kNone;
+        if (__ballot(holding) == 0) break; // every ray of the wave ran out of nodes
+        if (holding) { // leaf, bvh.rs:763-776
             bool stop = false;
-            for (uint32_t i = 0; i < leaf_cnt; i++) {
-                LeafPrim lp = S.leaf[leaf_off + i];
+            for (uint32_t i = cur & ~kLeafRef;; i++) {
+                LeafPrim lp = S.leaf[i];
                 float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 if (COUNT) {
                     uint32_t k = lp.kind & 7u;
@@ -167,18 +244,13 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
                 }
                 if (prim_test(S, lp, ray, t, b0, b1, b2)) {
                     ray.t_max = t;
-                    best = leaf_off + i;
+                    best = i;
                     a0 = b0; a1 = b1; a2 = b2;
                     if (ANY) { stop = true; break; }
                 }
+                if (lp.kind & kLastInLeaf) break;
             }
-            leaf_cnt = 0;
-            if (stop || sp == 0) {
-                cur = kNone;
-            } else {
-                sp--;
-                cur = stack[sp * kStride];
-            }
+            cur = stop ? kNone : pop();
         }
     }
     return best;
@@ -630,10 +702,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev F, const float4 *ra
 }
 
 // ---- host-side launchers ------------------------------------------------------------------------------
-// dynamic LDS: stacks only, or nodes + 16-bit stacks for the LDS-resident shape
-static inline size_t lds_bytes(const LaunchShape &L, uint32_t n_nodes) {
-    return L.lds_nodes ? (size_t)n_nodes * 32 + (size_t)L.slots * 1024 * sizeof(uint16_t)
-                       : (size_t)L.slots * kBlock * sizeof(uint32_t);
+// dynamic LDS: the LDS part of the stacks (child reference + entry distance per level and
+// lane), preceded by the interior records for the LDS-resident shape
+size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds) {
+    return lds_nodes ? (size_t)n_pairs * 64 + (size_t)stack_lds * 1024 * (sizeof(float) + sizeof(uint16_t))
+                     : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t));
 }
 
 template <class K>
@@ -656,7 +729,7 @@ hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ra
     uint32_t blocks = (n + threads - 1) / threads;
     if (blocks > L.grid) blocks = L.grid;
     if (blocks == 0) return hipSuccess;
-    const size_t lds = lds_bytes(L, S.n_nodes);
+    const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) {
         if (counters) RT_LAUNCH((k_intersect<true, true>), blocks, threads, S, rays, n, hits, counters);
         else RT_LAUNCH((k_intersect<false, true>), blocks, threads, S, rays, n, hits, counters);
@@ -673,7 +746,7 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
     uint32_t blocks = (n + threads - 1) / threads;
     if (blocks > L.grid) blocks = L.grid;
     if (blocks == 0) return hipSuccess;
-    const size_t lds = lds_bytes(L, S.n_nodes);
+    const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out);
     else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out);
     return hipGetLastError();
@@ -698,7 +771,7 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
                          unsigned long long *counters, hipStream_t stream) {
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
-    const size_t lds = lds_bytes(L, S.n_nodes);
+    const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) {
         if (counters)
             RT_LAUNCH((k_bounce<true, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,

@@ -36,10 +36,15 @@ struct FrameDev {
 
 // How the trace kernels are launched for one scene on one device.
 struct LaunchShape {
-    uint32_t slots;  // traversal stack entries per lane
+    uint32_t slots;  // traversal stack entries a lane can need
     uint32_t grid;   // persistent workgroups
     bool lds_nodes;  // node array staged in LDS (1024-thread workgroups), else 256-thread workgroups
 };
+
+// Stack entries a lane can keep in a private array beyond its LDS levels.
+constexpr uint32_t kSpillLevels = 56;
+// Dynamic LDS of a trace workgroup (interior records for the LDS-resident shape + stacks).
+size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds);
 
 hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n,
                             rt_hit *hits, unsigned long long *counters, hipStream_t stream);
