@@ -397,7 +397,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     memcpy(D.background, s.background, sizeof D.background);
 
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&p, 32 * sizeof(unsigned long long)));
     db.allocs.push_back(p);
     db.counters = static_cast<unsigned long long *>(p);
 
@@ -635,7 +635,7 @@ int rt_intersect_count(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hi
     if (rc != RT_OK) return rc;
     if (!out || (n && (!d_rays || !d_hits))) return fail(RT_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> g(db->render_lock);
-    HIP_TRY(hipMemset(db->counters, 0, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(db->counters, 0, 32 * sizeof(unsigned long long)));
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
         HIP_TRY(rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at,
@@ -766,7 +766,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     HIP_TRY(hipEventCreate(&ev_begin));
     HIP_TRY(hipEventCreate(&ev_end));
     HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)o->width * o->height * 4 * sizeof(float), st));
-    if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, 16 * sizeof(unsigned long long), st));
+    if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, 32 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ev_begin, st));
     uint64_t segments = 0, paths = 0, launches = 0;
     uint32_t batches = 0, max_bounce = 0;
@@ -832,6 +832,13 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
             stats->nodes_visited = c[0];
             for (int k = 0; k < 8; k++) stats->prims_tested[k] = c[1 + k];
+#ifdef RT_PROFILE
+            unsigned long long pr[12];
+            HIP_TRY(hipMemcpy(pr, db->counters + 16, sizeof pr, hipMemcpyDeviceToHost));
+            fprintf(stderr, "rt355 profile:");
+            for (int k = 0; k < 12; k++) fprintf(stderr, " %llu", pr[k]);
+            fprintf(stderr, "\n");
+#endif
         }
     }
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);

@@ -105,9 +105,22 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
     return v;
 }
 
+// Build with -DRT_PROFILE to have the counting kernels also time their phases
+// (shader clock) and tally lane occupancy; rt_render_dev prints the totals.
+#ifdef RT_PROFILE
+#define PROF(...) __VA_ARGS__
+#else
+#define PROF(...)
+#endif
+
 struct Counters {
     uint32_t nodes;
     uint32_t prims[8];
+    // 0 node-loop iterations, 1 lanes stepping in them, 2 leaf rounds, 3 primitive iterations
+    // of leaf rounds (longest lane), 4 lanes x primitives tested, 5 cycles in node loops,
+    // 6 cycles in leaf rounds, 7 cycles in traverse, 8 cycles shading, 9 cycles per chunk,
+    // 10 chunks, 11 rays
+    PROF(unsigned long long p[12];)
 };
 
 // <BVH as Primitive>::intersect, shapes/src/bvh.rs:736-799, with the ray
@@ -187,14 +200,17 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
         float4 r1 = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
         if (slab(r0, r1, ray, inv, negx, negy, negz, t)) cur = S.root_ref;
     }
+    PROF(const unsigned long long tp0 = __builtin_amdgcn_s_memtime();)
     for (;;) {
         // interior steps: lanes that hold a leaf wait here until kLeafLanes of them do (or
         // nobody can step any more)
+        PROF(const unsigned long long tn0 = __builtin_amdgcn_s_memtime();)
         for (;;) {
             const bool stepping = (cur >> 31) == 0;
             const bool holding = !stepping && cur != kNone;
             if (__ballot(stepping) == 0) break;
             if ((uint32_t)__popcll(__ballot(holding)) >= kLeafLanes) break;
+            PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
             if (stepping) {
                 float4 q0, q1, q2, q3;
                 if constexpr (LDSN) {
@@ -231,10 +247,13 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
             }
         }
         const bool holding = (cur >> 31) != 0 && cur != kNone;
+        PROF(const unsigned long long tl0 = __builtin_amdgcn_s_memtime(); if (COUNT) cnt.p[5] += tl0 - tn0;)
         if (__ballot(holding) == 0) break; // every ray of the wave ran out of nodes
+        PROF(uint32_t my_iters = 0;)
         if (holding) { // leaf, bvh.rs:763-776
             bool stop = false;
             for (uint32_t i = cur & ~kLeafRef;; i++) {
+                PROF(my_iters++;)
                 LeafPrim lp = S.leaf[i];
                 float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
                 if (COUNT) {
@@ -252,7 +271,16 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
             }
             cur = stop ? kNone : pop();
         }
+        PROF(if (COUNT) {
+            uint32_t longest = my_iters;
+            for (int sh = 32; sh > 0; sh >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, sh, 64));
+            cnt.p[2]++;
+            cnt.p[3] += longest;
+            cnt.p[4] += my_iters;
+            cnt.p[6] += __builtin_amdgcn_s_memtime() - tl0;
+        })
     }
+    PROF(if (COUNT) cnt.p[7] += __builtin_amdgcn_s_memtime() - tp0;)
     return best;
 }
 
@@ -277,6 +305,13 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
         for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[k], (unsigned long long)x);
     }
+    PROF(for (int k = 0; k < 12; k++) {
+        unsigned long long x = c.p[k];
+        const bool per_lane = k == 1 || k == 4 || k == 11;
+        if (per_lane)
+            for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[16 + k], x);
+    })
 }
 
 template <bool COUNT, bool LDSN>
@@ -569,6 +604,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) 
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
     for (uint32_t c = wave_index(); c < n_chunks; c += wave_total()) {
+        PROF(const unsigned long long tc0 = __builtin_amdgcn_s_memtime(); unsigned long long ts0 = tc0;)
         const uint32_t shard = c % kShards;
         const uint32_t i = (c / kShards) * 64 + lane;
         const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
@@ -599,6 +635,8 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) 
             const Ray ray0 = ray;
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
             uint32_t slot = traverse<false, COUNT, LDSN>(S, tv, ray, a0, a1, a2, cnt);
+            PROF(ts0 = __builtin_amdgcn_s_memtime();)
+            PROF(if (COUNT) cnt.p[11]++;)
             if (slot == RT_MISS) {
                 radiance[local] = make_float4(beta.x * S.background[0], beta.y * S.background[1],
                                               beta.z * S.background[2], 0.0f);
@@ -672,6 +710,14 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) 
             if (alive)
                 queue_push(qout, (size_t)shard * qout.cap + base + lane_rank(mask), ray, local, beta, rng, gpath);
         }
+        PROF(if (COUNT) {
+            const unsigned long long te = __builtin_amdgcn_s_memtime();
+            uint32_t shade = (uint32_t)(te - ts0); // lanes without a ray still hold the chunk's start
+            for (int sh = 32; sh > 0; sh >>= 1) shade = min(shade, (uint32_t)__shfl_xor(shade, sh, 64));
+            cnt.p[8] += shade;
+            cnt.p[9] += te - tc0;
+            cnt.p[10]++;
+        })
     }
     if (COUNT) flush_counters(cnt, counters);
 }
