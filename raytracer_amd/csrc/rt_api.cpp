@@ -87,6 +87,7 @@ struct DeviceBuffers {
     rt::SceneDev dev{};
     rt::LaunchShape shape{};
     unsigned long long *counters = nullptr;
+    uint8_t *bounce_scratch = nullptr; // per-wave parking and save areas of the bounce kernel
     uint64_t bytes = 0;
     // render workspace (grown on demand)
     std::mutex render_lock;
@@ -262,8 +263,25 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     uint32_t n_pairs = 0;
     for (size_t i = 0; i < nodes.size(); i++)
         if (nodes[i].primitive_count == 0) record_of[i] = n_pairs++;
+    // primitives the plain shader does not cover by kind
+    auto rare_prim = [&](const rt_prim_ref &pr) {
+        const uint32_t kind = pr.kind & 0xffu;
+        return pr.xform != 0 || !(kind == RT_SPHERE || kind == RT_TRIANGLE || kind == RT_RECT || kind == RT_BOX);
+    };
     auto ref_of = [&](size_t i) {
         return nodes[i].primitive_count ? (rt::kLeafRef | nodes[i].child_offset) : record_of[i];
+    };
+    // which hits the plain shader covers: see kRareShade
+    auto solid = [&](uint32_t t) { return t < s.textures.size() && s.textures[t].kind == RT_TEX_SOLID; };
+    auto rare_shade = [&](const rt_prim_ref &pr) {
+        if (rare_prim(pr)) return true;
+        if (pr.material >= s.materials.size()) return true; // intersection-only scene: never shaded
+        const rt_material &m = s.materials[pr.material];
+        if (m.texture >= s.textures.size()) return true;
+        if (!(m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_DIFFUSE_LIGHT))
+            return true;
+        const rt_texture &t = s.textures[m.texture];
+        return !(t.kind == RT_TEX_SOLID || (t.kind == RT_TEX_CHECKER && solid(t.a) && solid(t.b)));
     };
     auto bits = [](uint32_t v) {
         float f;
@@ -302,7 +320,8 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         const uint32_t id = s.tree.order[k];
         const rt_prim_ref &pr = s.prims[id];
         const uint32_t kind = pr.kind & 0xffu;
-        rt::LeafPrim lp{(pr.kind & 0x1ffu) | (pr.xform << 16), 0, id, pr.material, make_float4(0, 0, 0, 0)};
+        rt::LeafPrim lp{(pr.kind & 0x1ffu) | (pr.xform << 16) | (rare_shade(pr) ? rt::kRareShade : 0u), 0, id,
+                        pr.material, make_float4(0, 0, 0, 0)};
         switch (kind) {
         case RT_SPHERE:
             lp.index = push_sphere(pr.index);
@@ -426,15 +445,23 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     D.stack_lds = stack_lds;
     db.shape.slots = slots;
     db.shape.lds_nodes = lds_nodes;
+    // The bounce kernel binds wave w to sub-queue w % kShards: the wave count of the grid
+    // (16 waves per 1024-thread workgroup, 4 per 256-thread one) is kept a multiple of kShards.
     if (lds_nodes) {
-        db.shape.grid = (uint32_t)prop.multiProcessorCount;
+        db.shape.grid = std::max(2u, (uint32_t)prop.multiProcessorCount / 2 * 2);
     } else {
         size_t lds = rt::lds_bytes(false, n_pairs, stack_lds);
         uint32_t per_cu = (uint32_t)(lds_cu / (lds ? lds : 1));
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
-        db.shape.grid = (uint32_t)prop.multiProcessorCount * per_cu;
+        db.shape.grid = std::max(8u, (uint32_t)prop.multiProcessorCount * per_cu / 8 * 8);
     }
+    static_assert(rt::kShards == 32, "grid rounding above assumes 32 sub-queues");
+    const size_t scratch_bytes = (size_t)rt::bounce_waves(db.shape) * rt::kWaveScratchBytes;
+    HIP_TRY(hipMalloc(&p, scratch_bytes));
+    db.allocs.push_back(p);
+    db.bounce_scratch = static_cast<uint8_t *>(p);
+    db.bytes += scratch_bytes;
     return RT_OK;
 }
 
@@ -789,7 +816,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             }
             HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
                                       db->counts, b, o->max_depth - 1, o->seed, db->radiance,
-                                      want_counters ? db->counters : nullptr, st));
+                                      db->bounce_scratch, want_counters ? db->counters : nullptr, st));
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
             launches++;
         }

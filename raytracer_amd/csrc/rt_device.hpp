@@ -16,7 +16,7 @@ namespace rt {
 
 // ---- resident scene (device pointers), passed to kernels by value --------------
 struct LeafPrim {      // one entry per primitive, in leaf order (BVH::primitives, bvh.rs:35)
-    uint32_t kind;     // rt_prim_kind | reverse << 8 | last-of-its-leaf << 9 | xform << 16
+    uint32_t kind;     // rt_prim_kind | reverse << 8 | kLastInLeaf | kRareShade | xform << 16
     uint32_t index;    // index into the typed table (tables are packed in leaf order)
     uint32_t prim;     // caller's primitive index
     uint32_t material;
@@ -24,6 +24,10 @@ struct LeafPrim {      // one entry per primitive, in leaf order (BVH::primitive
 };
 
 constexpr uint32_t kLastInLeaf = 0x200u; // LeafPrim.kind: no further primitive in this leaf
+// LeafPrim.kind: a hit on this primitive needs the general shader (anything but a sphere,
+// triangle, rectangle or box without instance transform, carrying a Lambertian, metallic
+// or emissive material whose texture is a solid colour or a 3-D checker of solid colours)
+constexpr uint32_t kRareShade = 0x400u;
 constexpr uint32_t kLeafRef = 0x80000000u; // child reference: leaf starting at primitive (ref & ~kLeafRef)
 
 struct GSphere { // derived form of rt_gsphere, 128 B
@@ -530,16 +534,19 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, flo
     }
 }
 
+template <bool WANT_UV = true>
 RT_DEV void sphere_surface(v3 oc, v3 d, v3 c, float r, float t, Surf &out) {
     float ar = fabsf(r);
     v3 p = oc + d * t;
     p = p * (ar / length(p));
     if (p.x == 0.0f && p.y == 0.0f) p.x = 1e-5f * ar;
-    float phi = p_atan2(p.y, p.x);
-    if (phi < 0.0f) phi += kTwoPi;
-    float theta = p_acos(clampf(p.z / ar, -1.0f, 1.0f));
-    out.u = phi / kTwoPi;
-    out.v = (theta - kPi) / (0.0f - kPi);
+    if (WANT_UV) {
+        float phi = p_atan2(p.y, p.x);
+        if (phi < 0.0f) phi += kTwoPi;
+        float theta = p_acos(clampf(p.z / ar, -1.0f, 1.0f));
+        out.u = phi / kTwoPi;
+        out.v = (theta - kPi) / (0.0f - kPi);
+    }
     out.n = p / r;
     out.p = p + c;
     v3 ap = vabs(p);
@@ -689,11 +696,78 @@ RT_DEV void prim_finalize(const SceneDev &S, const LeafPrim &lp, const Ray &ray,
     }
 }
 
+// prim_finalize for the hits the plain shader takes (no kRareShade): the four kinds without
+// instance transform, and no surface (u, v), which only image and uv-checker textures read.
+// Point, error bound and normal come out of the same arithmetic as above.
+RT_DEV void prim_finalize_plain(const SceneDev &S, const LeafPrim &lp, const Ray &ray, float t, float a0,
+                                float a1, float a2, Surf &out) {
+    uint32_t kind = lp.kind & 0xffu;
+    bool reverse = (lp.kind & RT_PRIM_REVERSE) != 0;
+    out.t = t;
+    out.flags = kind;
+    out.u = 0.0f;
+    out.v = 0.0f;
+    if (kind == RT_SPHERE) {
+        float4 sp = lp.geom;
+        v3 c = mk(sp.x, sp.y, sp.z);
+        sphere_surface<false>(ray.o - c, ray.d, c, sp.w, t, out);
+    } else if (kind == RT_BOX) {
+        rt_box bx = S.boxes[lp.index];
+        int face = (int)a0;
+        int ax = face >> 1, A, B;
+        rect_axes((uint32_t)ax, A, B);
+        float ta = t * comp(ray.d, A), tb = t * comp(ray.d, B);
+        float pa = comp(ray.o, A) + ta, pb = comp(ray.o, B) + tb;
+        float pk = (face & 1) ? bx.hi[ax] : bx.lo[ax];
+        float ea = (fabsf(comp(ray.o, A)) + fabsf(ta)) * G5;
+        float eb = (fabsf(comp(ray.o, B)) + fabsf(tb)) * G5;
+        float ek = fabsf(pk) * G5;
+        float nk = (face & 1) ? 1.0f : -1.0f;
+        if (ax == 0) { out.p = mk(pk, pa, pb); out.perr = mk(ek, ea, eb); out.n = mk(nk, 0.0f, 0.0f); }
+        else if (ax == 1) { out.p = mk(pa, pk, pb); out.perr = mk(ea, ek, eb); out.n = mk(0.0f, nk, 0.0f); }
+        else { out.p = mk(pa, pb, pk); out.perr = mk(ea, eb, ek); out.n = mk(0.0f, 0.0f, nk); }
+    } else if (kind == RT_TRIANGLE) {
+        const float4 *v = S.tris + 3 * (size_t)lp.index;
+        float4 q0 = v[0], q1 = v[1], q2 = v[2];
+        v3 p0 = mk(q0.x, q0.y, q0.z), p1 = mk(q1.x, q1.y, q1.z), p2 = mk(q2.x, q2.y, q2.z);
+        float b0 = a0, b1 = a1, b2 = a2;
+        out.p = mk(p0.x * b0 + p1.x * b1 + p2.x * b2, p0.y * b0 + p1.y * b1 + p2.y * b2,
+                   p0.z * b0 + p1.z * b1 + p2.z * b2);
+        out.perr = mk(fabsf(p0.x * b0) + fabsf(p1.x * b1) + fabsf(p2.x * b2),
+                      fabsf(p0.y * b0) + fabsf(p1.y * b1) + fabsf(p2.y * b2),
+                      fabsf(p0.z * b0) + fabsf(p1.z * b1) + fabsf(p2.z * b2)) * G7;
+        v3 n = normalize(cross(p0 - p2, p1 - p2));
+        if (S.tri_normals) {
+            const float *nn = S.tri_normals + 9 * (size_t)lp.index;
+            v3 ns = normalize(mk(nn[0] * b0 + nn[3] * b1 + nn[6] * b2, nn[1] * b0 + nn[4] * b1 + nn[7] * b2,
+                                 nn[2] * b0 + nn[5] * b1 + nn[8] * b2));
+            if (dot(n, ns) < 0.0f) n = -n;
+        } else if (reverse) {
+            n = -n;
+        }
+        out.n = n;
+    } else { // RT_RECT
+        rt_rect r = S.rects[lp.index];
+        int A, B;
+        rect_axes(r.axis, A, B);
+        float ta = t * comp(ray.d, A), tb = t * comp(ray.d, B);
+        float pa = comp(ray.o, A) + ta, pb = comp(ray.o, B) + tb;
+        float ea = (fabsf(comp(ray.o, A)) + fabsf(ta)) * G5;
+        float eb = (fabsf(comp(ray.o, B)) + fabsf(tb)) * G5;
+        float ek = fabsf(r.k) * G5;
+        float nk = reverse ? -1.0f : 1.0f;
+        if (r.axis == 0) { out.p = mk(r.k, pa, pb); out.perr = mk(ek, ea, eb); out.n = mk(nk, 0.0f, 0.0f); }
+        else if (r.axis == 1) { out.p = mk(pa, r.k, pb); out.perr = mk(ea, ek, eb); out.n = mk(0.0f, nk, 0.0f); }
+        else { out.p = mk(pa, pb, r.k); out.perr = mk(ea, eb, ek); out.n = mk(0.0f, 0.0f, nk); }
+    }
+}
+
 // ---- slab test, geometry/src/bounds3.rs:212-238 ------------------------------------------
 // Bounds3::intersect_inv, geometry/src/bounds3.rs:212-238.  t_near is the entry
 // distance the final comparison `t_near < ray.t_max` used: the only term of the
 // test that depends on ray.t_max, so a caller that keeps it can repeat the test
 // against a shortened ray without the box.
+#ifdef RT_SLAB_BRANCHY
 RT_DEV bool slab(float4 n0, float4 n1, const Ray &ray, v3 inv, bool negx, bool negy, bool negz, float &t_near) {
     const float g = 1.0f + 2.0f * G3;
     float t_min = ((negx ? n1.x : n0.x) - ray.o.x) * inv.x;
@@ -714,5 +788,30 @@ RT_DEV bool slab(float4 n0, float4 n1, const Ray &ray, v3 inv, bool negx, bool n
     t_near = t_min;
     return t_min < ray.t_max && t_max > 0.0f;
 }
+#else
+RT_DEV bool slab(float4 n0, float4 n1, const Ray &ray, v3 inv, bool negx, bool negy, bool negz, float &t_near) {
+    // straight-line form: the reference's early returns only skip work, the outcome is the
+    // conjunction of its three conditions
+    const float g = 1.0f + 2.0f * G3;
+    float t_min = ((negx ? n1.x : n0.x) - ray.o.x) * inv.x;
+    float t_max = ((negx ? n0.x : n1.x) - ray.o.x) * inv.x;
+    float ty_min = ((negy ? n1.y : n0.y) - ray.o.y) * inv.y;
+    float ty_max = ((negy ? n0.y : n1.y) - ray.o.y) * inv.y;
+    float tz_min = ((negz ? n1.z : n0.z) - ray.o.z) * inv.z;
+    float tz_max = ((negz ? n0.z : n1.z) - ray.o.z) * inv.z;
+    t_max *= g;
+    ty_max *= g;
+    tz_max *= g;
+    const bool miss_xy = t_min > ty_max || ty_min > t_max;
+    t_min = sel_max(t_min, ty_min);
+    t_max = sel_min(t_max, ty_max);
+    const bool miss_z = t_min > tz_max || tz_min > t_max;
+    t_min = sel_max(t_min, tz_min);
+    t_max = sel_min(t_max, tz_max);
+    t_near = t_min;
+    return !miss_xy && !miss_z && t_min < ray.t_max && t_max > 0.0f;
+}
+
+#endif
 
 } // namespace rt

@@ -28,7 +28,7 @@ constexpr int kBlock = 256;
 #endif
 // lanes holding a leaf that trigger a leaf round (64 = wait for every lane)
 #ifndef RT_LEAF_LANES
-#define RT_LEAF_LANES 24
+#define RT_LEAF_LANES 32
 #endif
 constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
 #ifndef RT_BOUNCE_WAVES
@@ -39,7 +39,10 @@ constexpr uint32_t kDead = 0xFFFFFFFFu;
 RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-RT_DEV uint32_t wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+// wave uniform by construction; readfirstlane tells the compiler so (scalar registers, scalar branches)
+RT_DEV uint32_t wave_index() {
+    return __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
 RT_DEV uint32_t wave_total() { return gridDim.x * (blockDim.x >> 6); }
 
 // Two launch shapes.  Trees whose interior records fit beside the stacks are
@@ -113,19 +116,76 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
 #define PROF(...)
 #endif
 
+// Cost probes (-DRT_DOUBLE_SHADE / _PRIM / _SLAB): the named piece runs a second time on
+// opaque copies of its inputs with its results thrown away, so that counter deltas between
+// builds measure that piece.  Never defined in the shipped library.
+RT_DEV float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 struct Counters {
     uint32_t nodes;
     uint32_t prims[8];
-    // 0 node-loop iterations, 1 lanes stepping in them, 2 leaf rounds, 3 primitive iterations
-    // of leaf rounds (longest lane), 4 lanes x primitives tested, 5 cycles in node loops,
-    // 6 cycles in leaf rounds, 7 cycles in traverse, 8 cycles shading, 9 cycles per chunk,
-    // 10 chunks, 11 rays
+    // 0 interior steps, 1 lanes stepping in them, 2 leaf rounds, 3 primitive iterations of
+    // leaf rounds (longest lane), 4 lanes x primitives tested, 5 cycles in interior steps,
+    // 6 cycles in leaf rounds, 8 cycles in feed turns, 9 cycles in all, 10 feed turns, 11 rays
     PROF(unsigned long long p[12];)
 };
 
-// <BVH as Primitive>::intersect, shapes/src/bvh.rs:736-799, with the ray
-// shortened on every accepted hit (ties go to the primitive tested later).
-// Returns the leaf slot of the winning primitive or RT_MISS.
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+// finished or empty lanes that trigger a refill while unread rays remain
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 32
+#endif
+constexpr uint32_t kRefillLanes = RT_REFILL_LANES;
+
+constexpr uint32_t kBestRare = 0x80000000u;
+
+// What a lane carries for the ray it is tracing.
+struct Lane {
+    Ray ray;       // t_max shrinks to the closest accepted hit
+    uint32_t best; // leaf slot of that hit (| kBestRare if it needs the general shader), or RT_MISS
+    float a0, a1, a2;
+    bool has_ray;
+};
+
+// A lane's whole traversal state.  cur: record index of the interior node to visit,
+// kLeafRef | first primitive of a leaf to test, or kNone when the ray is finished (or
+// the lane has none); sp: stacked far children.
+struct Trav {
+    Lane L;
+    v3 inv; // 1 / direction, bvh.rs:741-750
+    uint32_t cur, sp;
+};
+
+// A wave's share of a ray array: blocks of 64 consecutive entries at a fixed
+// stride, consumed front to back a few entries at a time.  All members are wave
+// uniform.
+struct Blocks {
+    uint32_t blk, off, n, stride;
+    RT_DEV bool more() const { return blk < n; }
+    // Hands the next unread entries to the lanes that want one, in lane order; kNone
+    // for a lane that gets none (the current block is used up first, so some lanes
+    // may have to ask again).
+    RT_DEV uint32_t take(bool want) {
+        const uint64_t m = __ballot(want);
+        const uint32_t len = blk < n ? min(64u, n - blk) : 0u;
+        const uint32_t avail = len - off;
+        const uint32_t rank = lane_rank(m);
+        const uint32_t idx = (want && rank < avail) ? blk + off + rank : kNone;
+        off += min((uint32_t)__popcll(m), avail);
+        if (len != 0 && off >= len) {
+            blk += stride;
+            off = 0;
+        }
+        return idx;
+    }
+};
+
+// <BVH as Primitive>::intersect / does_intersect, shapes/src/bvh.rs:736-863, for a
+// stream of rays, with the ray shortened on every accepted hit (ties go to the
+// primitive tested later).
 //
 // Same visiting order and the same box and primitive tests per ray as the
 // reference loop, re-associated so that one step handles an interior node's two
@@ -140,14 +200,25 @@ struct Counters {
 // A child whose box fails is never stacked; the reference would pop it, test
 // it and discard it, so the visit counter still counts both children.
 //
-// Scheduled for a 64-wide wave: every lane walks interior records until it
-// holds a leaf (or runs out of nodes), then the lanes that hold a leaf test its
-// primitives together, so the primitive code (a switch over seven kinds) runs
-// once per leaf round instead of once per node step.
-template <bool ANY, bool COUNT, bool LDSN>
-RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, float &a0, float &a1, float &a2,
-                         Counters &cnt) {
-    constexpr uint32_t kNone = 0xFFFFFFFFu;
+// Scheduled for a 64-wide wave.  Each lane is stepping (at an interior record),
+// holding (at a leaf), or free (its ray is finished, or it has none).  Every
+// turn of the loop the wave does one thing, chosen by head count:
+//   * enough free lanes and unread rays left (or nothing else to do): `feed`
+//     takes the finished rays' results and hands out new rays;
+//   * enough lanes holding a leaf (or nobody stepping): those lanes test their
+//     leaf's primitives, so the primitive code (a switch over seven kinds) runs
+//     for many lanes at once;
+//   * otherwise one interior step for the stepping lanes.
+// Rays therefore enter and leave a wave one by one instead of in groups of 64:
+// a long traversal does not hold 63 finished lanes idle.
+//
+// Feed: bool more() (wave uniform: unread rays remain),
+// bool turn(Trav &, bool free): for free lanes, consume the finished ray if
+// L.has_ray, then load the next ray or clear has_ray; returns true on lanes that
+// received a ray (it may save the whole of Trav to memory and reload it), and
+// void finish(), called once when every ray of the wave has been consumed.
+template <bool ANY, bool COUNT, bool LDSN, class Feed>
+RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt) {
     constexpr int kStride = Shape<LDSN>::kThreads;
     using RefT = typename Shape<LDSN>::RefT;
     RefT *const s_ref = tv.ref;
@@ -155,9 +226,19 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
     const uint32_t levels = tv.levels;
     uint32_t spill_ref[kSpill];
     float spill_near[kSpill];
-    v3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z); // bvh.rs:741-750
-    bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
-    uint32_t sp = 0, cur = kNone, best = RT_MISS;
+    Trav T;
+    Lane &L = T.L;
+    v3 &inv = T.inv;
+    uint32_t &sp = T.sp, &cur = T.cur;
+    L.has_ray = false;
+    L.best = RT_MISS;
+    L.a0 = L.a1 = L.a2 = 0.0f;
+    L.ray.o = L.ray.d = mk(0.0f, 0.0f, 0.0f);
+    L.ray.t_max = L.ray.time = 0.0f;
+    inv = mk(0.0f, 0.0f, 0.0f);
+    bool negx = false, negy = false, negz = false;
+    sp = 0;
+    cur = kNone;
 
     auto push = [&](uint32_t r, float t) {
         if (sp < levels) {
@@ -175,17 +256,18 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
         uint32_t r = kNone;
         while (sp > 0) {
             sp--;
-            uint32_t e;
-            float t;
-            if (sp < levels) {
-                e = s_ref[sp * kStride];
-                if constexpr (LDSN) e = (e & 0x7fffu) | ((e & 0x8000u) << 16);
-                t = s_near[sp * kStride];
-            } else {
+            // the LDS read is unconditional (clamped level) and the private array is read in
+            // its own branch: two address spaces behind one selected pointer would turn both
+            // into slow generic loads
+            const uint32_t level = sp < levels ? sp : levels - 1;
+            uint32_t e = s_ref[level * kStride];
+            float t = s_near[level * kStride];
+            if constexpr (LDSN) e = (e & 0x7fffu) | ((e & 0x8000u) << 16);
+            if (sp >= levels) {
                 e = spill_ref[sp - levels];
                 t = spill_near[sp - levels];
             }
-            if (t < ray.t_max) {
+            if (t < L.ray.t_max) {
                 r = e;
                 break;
             }
@@ -193,95 +275,157 @@ RT_DEV uint32_t traverse(const SceneDev &S, const TreeView<LDSN> &tv, Ray &ray, 
         return r;
     };
 
-    if (S.n_nodes) { // the root's own box, bvh.rs:757-762
-        if (COUNT) cnt.nodes++;
-        float t;
-        float4 r0 = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f);
-        float4 r1 = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
-        if (slab(r0, r1, ray, inv, negx, negy, negz, t)) cur = S.root_ref;
-    }
-    PROF(const unsigned long long tp0 = __builtin_amdgcn_s_memtime();)
+    PROF(unsigned long long tp = __builtin_amdgcn_s_memtime(); const unsigned long long tp0 = tp;)
     for (;;) {
-        // interior steps: lanes that hold a leaf wait here until kLeafLanes of them do (or
-        // nobody can step any more)
-        PROF(const unsigned long long tn0 = __builtin_amdgcn_s_memtime();)
+        {
+            const bool busy = cur != kNone;
+            const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+            if (n_busy == 0 || (64u - n_busy >= kRefillLanes && feed.more())) {
+                const bool fresh = feed.turn(T, !busy);
+                if (fresh) { // bvh.rs:741-762: reciprocal direction, then the root's own box
+                    inv = mk(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+                    sp = 0;
+                    L.best = RT_MISS;
+                    if (S.n_nodes) {
+                        if (COUNT) cnt.nodes++;
+                        float t;
+                        float4 r0 = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f);
+                        float4 r1 = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
+                        if (slab(r0, r1, L.ray, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f, t)) cur = S.root_ref;
+                    }
+                    PROF(if (COUNT) cnt.p[11]++;)
+                }
+                negx = inv.x < 0.0f;
+                negy = inv.y < 0.0f;
+                negz = inv.z < 0.0f;
+                PROF(if (COUNT) {
+                    const unsigned long long t = __builtin_amdgcn_s_memtime();
+                    cnt.p[8] += t - tp;
+                    cnt.p[10]++;
+                    tp = t;
+                })
+                if (__ballot(L.has_ray) == 0) {
+                    if (feed.more()) continue; // only dead entries came: ask again
+                    break;
+                }
+            }
+        }
+        // interior steps, bvh.rs:778-795 for both children, until enough lanes hold a leaf,
+        // enough lanes are free for a refill, or nobody is left stepping
+        const bool can_refill = feed.more();
         for (;;) {
             const bool stepping = (cur >> 31) == 0;
-            const bool holding = !stepping && cur != kNone;
-            if (__ballot(stepping) == 0) break;
-            if ((uint32_t)__popcll(__ballot(holding)) >= kLeafLanes) break;
+            const uint64_t m_step = __ballot(stepping);
+            if (m_step == 0) break;
+            const uint32_t n_step = (uint32_t)__popcll(m_step);
+            const uint32_t n_hold = (uint32_t)__popcll(__ballot(!stepping && cur != kNone));
+            if (n_hold >= kLeafLanes) break;
+            if (can_refill && 64u - n_step - n_hold >= kRefillLanes) break;
             PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
             if (stepping) {
-                float4 q0, q1, q2, q3;
-                if constexpr (LDSN) {
-                    const float4 *q = tv.q + cur;
-                    const uint32_t n = tv.n_pairs;
-                    q0 = q[0];
-                    q1 = q[n];
-                    q2 = q[2 * (size_t)n];
-                    q3 = q[3 * (size_t)n];
-                } else {
-                    const float4 *q = S.nodes + 4 * (size_t)cur;
-                    q0 = q[0];
-                    q1 = q[1];
-                    q2 = q[2];
-                    q3 = q[3];
+                bool need_pop = true;
+                {
+                    float4 q0, q1, q2, q3;
+                    if constexpr (LDSN) {
+                        const float4 *q = tv.q + cur;
+                        const uint32_t n = tv.n_pairs;
+                        q0 = q[0];
+                        q1 = q[n];
+                        q2 = q[2 * (size_t)n];
+                        q3 = q[3 * (size_t)n];
+                    } else {
+                        const float4 *q = S.nodes + 4 * (size_t)cur;
+                        q0 = q[0];
+                        q1 = q[1];
+                        q2 = q[2];
+                        q3 = q[3];
+                    }
+                    if (COUNT) cnt.nodes += 2;
+                    float t0, t1;
+#ifdef RT_DOUBLE_SLAB
+                    {
+                        float4 p0 = q0, p1 = q1, p2 = q2, p3 = q3;
+                        p0.x = opaque(p0.x); p1.x = opaque(p1.x); p2.x = opaque(p2.x); p3.x = opaque(p3.x);
+                        float u0, u1;
+                        bool g0 = slab(p0, p1, L.ray, inv, negx, negy, negz, u0);
+                        bool g1 = slab(p2, p3, L.ray, inv, negx, negy, negz, u1);
+                        float sink = (g0 ? u0 : 0.0f) + (g1 ? u1 : 0.0f);
+                        asm volatile("" ::"v"(sink));
+                    }
+#endif
+                    const bool h0 = slab(q0, q1, L.ray, inv, negx, negy, negz, t0);
+                    const bool h1 = slab(q2, q3, L.ray, inv, negx, negy, negz, t1);
+                    const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+                    const uint32_t axis = __float_as_uint(q2.w);
+                    const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz); // second child is nearer
+                    if (h0 && h1) {
+                        push(neg ? r0 : r1, neg ? t0 : t1);
+                        cur = neg ? r1 : r0;
+                        need_pop = false;
+                    } else if (h0 || h1) {
+                        cur = h0 ? r0 : r1;
+                        need_pop = false;
+                    }
                 }
-                if (COUNT) cnt.nodes += 2;
-                float t0, t1;
-                const bool h0 = slab(q0, q1, ray, inv, negx, negy, negz, t0);
-                const bool h1 = slab(q2, q3, ray, inv, negx, negy, negz, t1);
-                const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
-                const uint32_t axis = __float_as_uint(q2.w);
-                const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz); // second child is nearer
-                if (h0 && h1) {
-                    push(neg ? r0 : r1, neg ? t0 : t1);
-                    cur = neg ? r1 : r0;
-                } else if (h0) {
-                    cur = r0;
-                } else if (h1) {
-                    cur = r1;
-                } else {
-                    cur = pop();
-                }
+                if (need_pop) cur = pop();
             }
-        }
-        const bool holding = (cur >> 31) != 0 && cur != kNone;
-        PROF(const unsigned long long tl0 = __builtin_amdgcn_s_memtime(); if (COUNT) cnt.p[5] += tl0 - tn0;)
-        if (__ballot(holding) == 0) break; // every ray of the wave ran out of nodes
-        PROF(uint32_t my_iters = 0;)
-        if (holding) { // leaf, bvh.rs:763-776
-            bool stop = false;
-            for (uint32_t i = cur & ~kLeafRef;; i++) {
-                PROF(my_iters++;)
-                LeafPrim lp = S.leaf[i];
-                float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
-                if (COUNT) {
-                    uint32_t k = lp.kind & 7u;
-#pragma unroll
-                    for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
-                }
-                if (prim_test(S, lp, ray, t, b0, b1, b2)) {
-                    ray.t_max = t;
-                    best = i;
-                    a0 = b0; a1 = b1; a2 = b2;
-                    if (ANY) { stop = true; break; }
-                }
-                if (lp.kind & kLastInLeaf) break;
-            }
-            cur = stop ? kNone : pop();
         }
         PROF(if (COUNT) {
-            uint32_t longest = my_iters;
-            for (int sh = 32; sh > 0; sh >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, sh, 64));
-            cnt.p[2]++;
-            cnt.p[3] += longest;
-            cnt.p[4] += my_iters;
-            cnt.p[6] += __builtin_amdgcn_s_memtime() - tl0;
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            cnt.p[5] += t - tp;
+            tp = t;
         })
+        // leaf round, bvh.rs:763-776: when enough lanes hold a leaf or nobody can step
+        const bool holding = (cur >> 31) != 0 && cur != kNone;
+        const uint32_t n_hold = (uint32_t)__popcll(__ballot(holding));
+        if (n_hold >= kLeafLanes || (n_hold != 0 && __ballot((cur >> 31) == 0) == 0)) {
+            PROF(uint32_t my_iters = 0;)
+            if (holding) {
+                bool stop = false;
+                for (uint32_t i = cur & ~kLeafRef;; i++) {
+                    PROF(my_iters++;)
+                    LeafPrim lp = S.leaf[i];
+                    float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                    if (COUNT) {
+                        uint32_t k = lp.kind & 7u;
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
+                    }
+#ifdef RT_DOUBLE_PRIM
+                    {
+                        Ray r2 = L.ray;
+                        r2.o.x = opaque(r2.o.x);
+                        float t2 = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+                        bool g = prim_test(S, lp, r2, t2, c0, c1, c2);
+                        float sink = g ? t2 + c0 + c1 + c2 : 0.0f;
+                        asm volatile("" ::"v"(sink));
+                    }
+#endif
+                    const bool hit = prim_test(S, lp, L.ray, t, b0, b1, b2);
+                    if (hit) {
+                        L.ray.t_max = t;
+                        L.best = i | ((lp.kind & kRareShade) ? kBestRare : 0u);
+                        L.a0 = b0; L.a1 = b1; L.a2 = b2;
+                        if (ANY) { stop = true; break; }
+                    }
+                    if (lp.kind & kLastInLeaf) break;
+                }
+                cur = stop ? kNone : pop();
+            }
+            PROF(if (COUNT) {
+                uint32_t longest = my_iters;
+                for (int sh = 32; sh > 0; sh >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, sh, 64));
+                cnt.p[2]++;
+                cnt.p[3] += longest;
+                cnt.p[4] += my_iters;
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                cnt.p[6] += t - tp;
+                tp = t;
+            })
+        }
     }
-    PROF(if (COUNT) cnt.p[7] += __builtin_amdgcn_s_memtime() - tp0;)
-    return best;
+    feed.finish();
+    PROF(if (COUNT) cnt.p[9] += __builtin_amdgcn_s_memtime() - tp0;)
 }
 
 RT_DEV Ray load_ray(const rt_ray *rays, size_t i) {
@@ -314,56 +458,82 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
     })
 }
 
-template <bool COUNT, bool LDSN>
-__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_intersect(
-    SceneDev S, const rt_ray *rays, uint32_t n, rt_hit *hits, unsigned long long *counters) {
-    const TreeView<LDSN> tv = tree_view<LDSN>(S);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t stride = wave_total() * 64;
-    Counters cnt = {};
-    for (uint32_t base = wave_index() * 64; base < n; base += stride) {
-        uint32_t i = base + lane;
-        if (i < n) {
-            Ray ray = load_ray(rays, i);
-            const Ray ray0 = ray;
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            uint32_t slot = traverse<false, COUNT, LDSN>(S, tv, ray, a0, a1, a2, cnt);
+// rt_intersect: hit records out, rays in
+struct HitFeed {
+    const SceneDev &S;
+    const rt_ray *rays;
+    rt_hit *hits;
+    Blocks blocks;
+    uint32_t idx;
+    RT_DEV bool more() const { return blocks.more(); }
+    RT_DEV bool turn(Trav &T, bool free) {
+        Lane &L = T.L;
+        if (free && L.has_ray) {
             float4 h0, h1;
-            if (slot != RT_MISS) {
-                LeafPrim lp = S.leaf[slot];
+            if (L.best != RT_MISS) {
+                LeafPrim lp = S.leaf[L.best & ~kBestRare];
                 Surf sf;
-                prim_finalize(S, lp, ray0, ray.t_max, a0, a1, a2, sf);
+                prim_finalize(S, lp, L.ray, L.ray.t_max, L.a0, L.a1, L.a2, sf);
                 h0 = make_float4(sf.t, __uint_as_float(lp.prim), sf.u, sf.v);
                 h1 = make_float4(sf.n.x, sf.n.y, sf.n.z, __uint_as_float(sf.flags));
             } else {
                 h0 = make_float4(kInf, __uint_as_float(RT_MISS), 0.0f, 0.0f);
                 h1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
-            float4 *o = reinterpret_cast<float4 *>(hits + i);
+            float4 *o = reinterpret_cast<float4 *>(hits + idx);
             o[0] = h0;
             o[1] = h1;
         }
+        const uint32_t next = blocks.take(free);
+        if (free) {
+            idx = next;
+            L.has_ray = next != kNone;
+            if (L.has_ray) L.ray = load_ray(rays, next);
+        }
+        return free && L.has_ray;
     }
+    RT_DEV void finish() {}
+};
+
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_intersect(
+    SceneDev S, const rt_ray *rays, uint32_t n, rt_hit *hits, unsigned long long *counters) {
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
+    Counters cnt = {};
+    HitFeed feed{S, rays, hits, Blocks{wave_index() * 64, 0u, n, wave_total() * 64}, kNone};
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt);
     if (COUNT) flush_counters(cnt, counters);
 }
+
+// rt_occluded: one byte per ray out
+struct AnyFeed {
+    const rt_ray *rays;
+    uint8_t *out;
+    Blocks blocks;
+    uint32_t idx;
+    RT_DEV bool more() const { return blocks.more(); }
+    RT_DEV bool turn(Trav &T, bool free) {
+        Lane &L = T.L;
+        if (free && L.has_ray) out[idx] = L.best != RT_MISS ? 1 : 0;
+        const uint32_t next = blocks.take(free);
+        if (free) {
+            idx = next;
+            L.has_ray = next != kNone;
+            if (L.has_ray) L.ray = load_ray(rays, next);
+        }
+        return free && L.has_ray;
+    }
+    RT_DEV void finish() {}
+};
 
 // <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
 template <bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_occluded(
     SceneDev S, const rt_ray *rays, uint32_t n, uint8_t *out) {
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t stride = wave_total() * 64;
     Counters cnt = {};
-    for (uint32_t base = wave_index() * 64; base < n; base += stride) {
-        uint32_t i = base + lane;
-        if (i < n) {
-            Ray ray = load_ray(rays, i);
-            float a0, a1, a2;
-            uint32_t slot = traverse<true, false, LDSN>(S, tv, ray, a0, a1, a2, cnt);
-            out[i] = slot != RT_MISS ? 1 : 0;
-        }
-    }
+    AnyFeed feed{rays, out, Blocks{wave_index() * 64, 0u, n, wave_total() * 64}, kNone};
+    trace_stream<true, false, LDSN>(S, tv, feed, cnt);
 }
 
 // ---- camera, colour/src/camera/perspective.rs:54-78 -----------------------------------------
@@ -505,8 +675,12 @@ RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
     float ww = w * w * (3.0f - 2.0f * w);
     const int32_t *px = S.perlin_perm, *py = S.perlin_perm + 256, *pz = S.perlin_perm + 512;
     float accum = 0.0f;
+    // rolled on purpose: noise is rare and must not set the kernel's register budget
+#pragma unroll 1
     for (int di = 0; di < 2; di++)
+#pragma unroll 1
         for (int dj = 0; dj < 2; dj++)
+#pragma unroll 1
             for (int dk = 0; dk < 2; dk++) {
                 int idx = px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255];
                 const float *c = S.perlin_vec + 3 * idx;
@@ -521,6 +695,7 @@ RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
 }
 RT_DEV float perlin_turb(const SceneDev &S, v3 p) {
     float accum = 0.0f, weight = 1.0f;
+#pragma unroll 1
     for (int i = 0; i < 7; i++) {
         accum += weight * perlin_noise(S, p);
         weight *= 0.5f;
@@ -585,17 +760,280 @@ RT_DEV v3 offset_origin(v3 p, v3 err, v3 n, v3 w) {
     return po;
 }
 
+// Texture of a plain hit: a solid colour, or a 3-D checker whose two cells are solid colours.
+RT_DEV v3 texture_plain(const SceneDev &S, uint32_t tex, v3 p) {
+    rt_texture t = S.textures[tex];
+    if (t.kind == RT_TEX_CHECKER) {
+        float sines = p_sin(t.scale * p.x) * p_sin(t.scale * p.y) * p_sin(t.scale * p.z);
+        t = S.textures[sines < 0.0f ? t.a : t.b];
+    }
+    return mk(t.rgb[0], t.rgb[1], t.rgb[2]);
+}
+
+// Shading of one finished path segment: emit, or scatter into the next ray
+// (L.ray.o / L.ray.d) with the throughput updated.  Returns whether the path
+// continues.  PLAIN: the hit does not carry kBestRare (or is a miss), so only the
+// four common primitive kinds, the three materials and the two texture forms that
+// flag leaves out can occur; the general code is the same computation with every
+// case present.
+template <bool PLAIN>
+RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local, float4 *radiance) {
+    if (L.best == RT_MISS) {
+        radiance[local] =
+            make_float4(beta.x * S.background[0], beta.y * S.background[1], beta.z * S.background[2], 0.0f);
+        return false;
+    }
+    bool alive = true;
+    LeafPrim lp = S.leaf[L.best & ~kBestRare];
+    Surf h;
+    if (PLAIN) prim_finalize_plain(S, lp, L.ray, L.ray.t_max, L.a0, L.a1, L.a2, h);
+    else prim_finalize(S, lp, L.ray, L.ray.t_max, L.a0, L.a1, L.a2, h);
+    const v3 d = L.ray.d;
+    const bool front = dot(d, h.n) < 0.0f;
+    const v3 nf = front ? h.n : -h.n;
+    const rt_material m = S.materials[lp.material];
+    // The pieces every material shares run once for the whole wave: the
+    // texture lookup (all but dielectrics) and the unit-sphere sample
+    // (Lambertian, metallic, isotropic).  Per path the RNG draws stay in
+    // the same order as when each material is evaluated on its own.
+    v3 tex = mk(1.0f, 1.0f, 1.0f), rs = mk(0.0f, 0.0f, 0.0f);
+    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
+        rs = random_in_unit_sphere(rng);
+    if (PLAIN) tex = texture_plain(S, m.texture, h.p);
+    else if (m.kind != RT_MAT_DIELECTRIC) tex = texture_value(S, m.texture, h.u, h.v, h.p);
+    v3 dir = nf;
+    if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
+        radiance[local] = make_float4(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z, 0.0f);
+        alive = false;
+    } else if (m.kind == RT_MAT_LAMBERTIAN) {
+        dir = nf + rs;
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = nf;
+    } else if (m.kind == RT_MAT_METALLIC) {
+        dir = reflect(d, nf) + rs * m.fuzz;
+        if (!(dot(dir, nf) > 0.0f)) alive = false; // absorbed
+    } else if (!PLAIN && m.kind == RT_MAT_DIELECTRIC) {
+        float ratio = front ? 1.0f / m.ior : m.ior;
+        float cos_t = sel_min(dot(-d, nf), 1.0f);
+        float sin_t = sqrtf(1.0f - cos_t * cos_t);
+        bool reflect_it = ratio * sin_t > 1.0f;
+        if (!reflect_it) {
+            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            r0 = r0 * r0;
+            float c5 = 1.0f - cos_t;
+            float refl = r0 + (1.0f - r0) * (c5 * c5 * c5 * c5 * c5);
+            reflect_it = refl > rng_f(rng);
+        }
+        if (reflect_it) {
+            dir = reflect(d, nf);
+        } else {
+            v3 perp = (d + nf * cos_t) * ratio;
+            float k = 1.0f - dot(perp, perp);
+            v3 par = nf * -sqrtf(fabsf(k));
+            dir = perp + par;
+        }
+    } else if (!PLAIN) { // RT_MAT_ISOTROPIC
+        dir = rs;
+    }
+    if (alive) {
+        dir = normalize(dir);
+        beta = mk(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z);
+        L.ray.o = offset_origin(h.p, h.perr, h.n, dir);
+        L.ray.d = dir;
+    }
+    return alive;
+}
+
+// One bounce: queued path segments in, shaded survivors compacted into the next
+// queue.  A wave reads and writes one sub-queue (its index modulo kShards).
+//
+// Shading is the most divergent and register-hungry code of the kernel, so it is
+// not run whenever a few rays finish.  A finished ray leaves a 24-byte record
+// (queue entry, winning leaf slot, t, three primitive-specific values) in one of
+// the wave's two parking lists and its lane is refilled at once.  List 0 takes
+// misses and hits the plain shader covers, list 1 the hits that need the general
+// shader (textures with lookups or noise, dielectrics, media, transformed or
+// moving primitives).  When a list holds 64 records the whole wave shades them
+// together: every lane of every shading instruction works, the short plain shader
+// runs for most rays, and the long general one runs once per 64 rays that need it
+// rather than whenever one ray of a wave does.  The lanes' traversal state is
+// written to memory around a shading batch and read back after it, so shading and
+// traversal do not compete for registers.
+struct BounceFeed {
+    const SceneDev &S;
+    const Queue &qin, &qout;
+    uint32_t *tail; // tail counter of the sub-queue written
+    size_t in_base, out_base;
+    Blocks blocks;
+    bool last; // depth exhausted after this bounce: survivors contribute nothing
+    uint64_t seed;
+    float4 *radiance;
+    float4 *park_a;     // 2 x kParkSlots x {entry, leaf slot, t, a0}
+    float2 *park_b;     // 2 x kParkSlots x {a1, a2}
+    uint32_t *save;     // kSaveWords x 64, word k of lane l at save[k * 64 + l]
+    uint32_t parked[2]; // wave uniform
+    uint32_t entry;     // queue entry of the ray this lane is tracing
+    RT_DEV bool more() const { return blocks.more(); }
+
+    RT_DEV void compact(bool alive, const Lane &P, uint32_t local, v3 beta, const Rng &rng, uint32_t gpath) {
+        // stream compaction: ballot, rank by prefix count, one atomic per wave on the tail
+        const uint64_t mask = __ballot(alive);
+        const uint32_t total = (uint32_t)__popcll(mask);
+        if (total) {
+            uint32_t base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(tail, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (alive) queue_push(qout, out_base + base + lane_rank(mask), P.ray, local, beta, rng, gpath);
+        }
+    }
+
+    template <bool PLAIN>
+    RT_DEV void shade_batch(uint32_t first, uint32_t count) {
+        const uint32_t lane = threadIdx.x & 63;
+        bool alive = false;
+        Lane P;
+        v3 beta = mk(0.0f, 0.0f, 0.0f);
+        Rng rng{0, 0};
+        uint32_t gpath = 0, local = kDead;
+        if (lane < count) {
+            const float4 ra = park_a[first + lane];
+            const float2 rb = park_b[first + lane];
+            const size_t e = in_base + __float_as_uint(ra.x);
+            const float4 qa = qin.a[e], qb = qin.b[e], qc = qin.c[e];
+            const uint2 qd = qin.d[e];
+            P.ray.o = mk(qa.x, qa.y, qa.z);
+            P.ray.time = qa.w;
+            P.ray.d = mk(qb.x, qb.y, qb.z);
+            P.ray.t_max = ra.z;
+            P.best = __float_as_uint(ra.y);
+            P.a0 = ra.w;
+            P.a1 = rb.x;
+            P.a2 = rb.y;
+            P.has_ray = true;
+            local = __float_as_uint(qb.w);
+            beta = mk(qc.x, qc.y, qc.z);
+            gpath = qd.y;
+            rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
+            rng.inc = (((seed << 32) + gpath) << 1) | 1u;
+#ifdef RT_DOUBLE_SHADE
+            {
+                Lane P2 = P;
+                P2.ray.o.x = opaque(P2.ray.o.x);
+                v3 beta2 = beta;
+                Rng rng2 = rng;
+                // radiance of an unused slot far away is not touched: hits on lights and misses
+                // write to `local`, so give the copy the same slot and let the real run overwrite it
+                bool g = shade<PLAIN>(S, P2, beta2, rng2, local, radiance);
+                float sink = g ? P2.ray.o.x + P2.ray.d.x + beta2.x : 0.0f;
+                asm volatile("" ::"v"(sink));
+            }
+#endif
+            alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && !last;
+        }
+        compact(alive, P, local, beta, rng, gpath);
+    }
+
+    RT_DEV bool turn(Trav &T, bool free) {
+        Lane &L = T.L;
+        const uint32_t lane = threadIdx.x & 63;
+        // park the finished rays
+        const bool finished = free && L.has_ray;
+        const bool general = L.best != RT_MISS && (L.best & kBestRare) != 0;
+        const uint64_t m0 = __ballot(finished && !general), m1 = __ballot(finished && general);
+        if (finished) {
+            const uint32_t slot = general ? kParkSlots + parked[1] + lane_rank(m1) : parked[0] + lane_rank(m0);
+            park_a[slot] = make_float4(__uint_as_float(entry), __uint_as_float(L.best), L.ray.t_max, L.a0);
+            park_b[slot] = make_float2(L.a1, L.a2);
+        }
+        parked[0] += (uint32_t)__popcll(m0);
+        parked[1] += (uint32_t)__popcll(m1);
+        if (parked[0] >= 64 || parked[1] >= 64) {
+            // the traversing lanes' state leaves the registers while a batch is shaded
+            uint32_t *sv = save + lane;
+            sv[0 * 64] = __float_as_uint(L.ray.o.x); sv[1 * 64] = __float_as_uint(L.ray.o.y);
+            sv[2 * 64] = __float_as_uint(L.ray.o.z); sv[3 * 64] = __float_as_uint(L.ray.d.x);
+            sv[4 * 64] = __float_as_uint(L.ray.d.y); sv[5 * 64] = __float_as_uint(L.ray.d.z);
+            sv[6 * 64] = __float_as_uint(L.ray.t_max); sv[7 * 64] = __float_as_uint(L.ray.time);
+            sv[8 * 64] = L.best; sv[9 * 64] = __float_as_uint(L.a0);
+            sv[10 * 64] = __float_as_uint(L.a1); sv[11 * 64] = __float_as_uint(L.a2);
+            sv[12 * 64] = __float_as_uint(T.inv.x); sv[13 * 64] = __float_as_uint(T.inv.y);
+            sv[14 * 64] = __float_as_uint(T.inv.z); sv[15 * 64] = T.cur;
+            sv[16 * 64] = T.sp; sv[17 * 64] = entry;
+            // the compiler must really store and reload (no forwarding through registers),
+            // and records parked by other lanes are read below
+            asm volatile("" ::: "memory");
+            __threadfence_block();
+            if (parked[0] >= 64) {
+                parked[0] -= 64;
+                shade_batch<true>(parked[0], 64);
+            }
+            if (parked[1] >= 64) {
+                parked[1] -= 64;
+                shade_batch<false>(kParkSlots + parked[1], 64);
+            }
+            asm volatile("" ::: "memory");
+            L.ray.o = mk(__uint_as_float(sv[0 * 64]), __uint_as_float(sv[1 * 64]), __uint_as_float(sv[2 * 64]));
+            L.ray.d = mk(__uint_as_float(sv[3 * 64]), __uint_as_float(sv[4 * 64]), __uint_as_float(sv[5 * 64]));
+            L.ray.t_max = __uint_as_float(sv[6 * 64]);
+            L.ray.time = __uint_as_float(sv[7 * 64]);
+            L.best = sv[8 * 64];
+            L.a0 = __uint_as_float(sv[9 * 64]);
+            L.a1 = __uint_as_float(sv[10 * 64]);
+            L.a2 = __uint_as_float(sv[11 * 64]);
+            T.inv = mk(__uint_as_float(sv[12 * 64]), __uint_as_float(sv[13 * 64]), __uint_as_float(sv[14 * 64]));
+            T.cur = sv[15 * 64];
+            T.sp = sv[16 * 64];
+            entry = sv[17 * 64];
+        }
+        // next rays
+        const uint32_t next = blocks.take(free);
+        bool fresh = false;
+        if (free) {
+            L.has_ray = false;
+            if (next != kNone) {
+                const float4 qa = qin.a[in_base + next], qb = qin.b[in_base + next];
+                if (__float_as_uint(qb.w) != kDead) {
+                    L.ray.o = mk(qa.x, qa.y, qa.z);
+                    L.ray.time = qa.w;
+                    L.ray.d = mk(qb.x, qb.y, qb.z);
+                    L.ray.t_max = kInf;
+                    entry = next;
+                    L.has_ray = true;
+                    fresh = true;
+                }
+            }
+        }
+        return fresh;
+    }
+
+    // after the last ray of the stream: shade what is still parked
+    RT_DEV void finish() {
+        __threadfence_block();
+        while (parked[0] != 0) {
+            const uint32_t count = parked[0] < 64u ? parked[0] : 64u;
+            parked[0] -= count;
+            shade_batch<true>(parked[0], count);
+        }
+        while (parked[1] != 0) {
+            const uint32_t count = parked[1] < 64u ? parked[1] : 64u;
+            parked[1] -= count;
+            shade_batch<false>(kParkSlots + parked[1], count);
+        }
+    }
+};
+
 // One bounce of every queued path: closest hit, shading, scatter, and the
 // survivors compacted into the next queue.  Radiance is stored once, when a
-// path ends on a light or leaves the scene.
+// path ends on a light or leaves the scene.  The launch must have a wave count
+// that is a multiple of kShards, so that wave w reads and writes sub-queue
+// w % kShards only.
 template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) void k_bounce(
     SceneDev S, Queue qin, Queue qout, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
-    float4 *radiance, unsigned long long *counters) {
+    float4 *radiance, uint8_t *scratch, unsigned long long *counters) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
     uint32_t *cout = counts + (size_t)(bounce + 1) * kShards * kCountStride;
-    // lane s holds the size of sub-queue s; the longest one bounds the chunk loop
+    // lane s holds the size of sub-queue s; the longest one tells which workgroups have work
     const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
     uint32_t longest = my_count;
     for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
@@ -603,122 +1041,14 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) 
     if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
-    for (uint32_t c = wave_index(); c < n_chunks; c += wave_total()) {
-        PROF(const unsigned long long tc0 = __builtin_amdgcn_s_memtime(); unsigned long long ts0 = tc0;)
-        const uint32_t shard = c % kShards;
-        const uint32_t i = (c / kShards) * 64 + lane;
-        const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
-        const size_t in_base = (size_t)shard * qin.cap;
-        bool alive = false;
-        Ray ray;
-        Rng rng;
-        v3 beta = mk(0.0f, 0.0f, 0.0f);
-        uint32_t local = kDead, gpath = 0;
-        if (i < n) {
-            float4 qb = qin.b[in_base + i];
-            local = __float_as_uint(qb.w);
-            if (local != kDead) {
-                float4 qa = qin.a[in_base + i], qc = qin.c[in_base + i];
-                uint2 qd = qin.d[in_base + i];
-                ray.o = mk(qa.x, qa.y, qa.z);
-                ray.time = qa.w;
-                ray.d = mk(qb.x, qb.y, qb.z);
-                ray.t_max = kInf;
-                beta = mk(qc.x, qc.y, qc.z);
-                gpath = qd.y;
-                rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
-                rng.inc = (((seed << 32) + gpath) << 1) | 1u;
-                alive = true;
-            }
-        }
-        if (alive) {
-            const Ray ray0 = ray;
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            uint32_t slot = traverse<false, COUNT, LDSN>(S, tv, ray, a0, a1, a2, cnt);
-            PROF(ts0 = __builtin_amdgcn_s_memtime();)
-            PROF(if (COUNT) cnt.p[11]++;)
-            if (slot == RT_MISS) {
-                radiance[local] = make_float4(beta.x * S.background[0], beta.y * S.background[1],
-                                              beta.z * S.background[2], 0.0f);
-                alive = false;
-            } else {
-                LeafPrim lp = S.leaf[slot];
-                Surf h;
-                prim_finalize(S, lp, ray0, ray.t_max, a0, a1, a2, h);
-                const v3 d = ray0.d;
-                const bool front = dot(d, h.n) < 0.0f;
-                const v3 nf = front ? h.n : -h.n;
-                const rt_material m = S.materials[lp.material];
-                // The pieces every material shares run once for the whole wave: the
-                // texture lookup (all but dielectrics) and the unit-sphere sample
-                // (Lambertian, metallic, isotropic).  Per path the RNG draws stay in
-                // the same order as when each material is evaluated on its own.
-                v3 tex = mk(1.0f, 1.0f, 1.0f), rs = mk(0.0f, 0.0f, 0.0f);
-                if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
-                    rs = random_in_unit_sphere(rng);
-                if (m.kind != RT_MAT_DIELECTRIC) tex = texture_value(S, m.texture, h.u, h.v, h.p);
-                v3 dir = nf;
-                if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
-                    radiance[local] = make_float4(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z, 0.0f);
-                    alive = false;
-                } else if (m.kind == RT_MAT_LAMBERTIAN) {
-                    dir = nf + rs;
-                    if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = nf;
-                } else if (m.kind == RT_MAT_METALLIC) {
-                    dir = reflect(d, nf) + rs * m.fuzz;
-                    if (!(dot(dir, nf) > 0.0f)) alive = false; // absorbed
-                } else if (m.kind == RT_MAT_DIELECTRIC) {
-                    float ratio = front ? 1.0f / m.ior : m.ior;
-                    float cos_t = sel_min(dot(-d, nf), 1.0f);
-                    float sin_t = sqrtf(1.0f - cos_t * cos_t);
-                    bool reflect_it = ratio * sin_t > 1.0f;
-                    if (!reflect_it) {
-                        float r0 = (1.0f - ratio) / (1.0f + ratio);
-                        r0 = r0 * r0;
-                        float c5 = 1.0f - cos_t;
-                        float refl = r0 + (1.0f - r0) * (c5 * c5 * c5 * c5 * c5);
-                        reflect_it = refl > rng_f(rng);
-                    }
-                    if (reflect_it) {
-                        dir = reflect(d, nf);
-                    } else {
-                        v3 perp = (d + nf * cos_t) * ratio;
-                        float k = 1.0f - dot(perp, perp);
-                        v3 par = nf * -sqrtf(fabsf(k));
-                        dir = perp + par;
-                    }
-                } else { // RT_MAT_ISOTROPIC
-                    dir = rs;
-                }
-                if (alive) {
-                    dir = normalize(dir);
-                    beta = mk(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z);
-                    ray.o = offset_origin(h.p, h.perr, h.n, dir);
-                    ray.d = dir;
-                    ray.t_max = kInf;
-                }
-            }
-            if (bounce == last) alive = false; // depth exhausted: the path contributes nothing
-        }
-        // stream compaction: ballot, rank by prefix count, one atomic per wave on the shard's tail
-        const uint64_t mask = __ballot(alive);
-        const uint32_t total = (uint32_t)__popcll(mask);
-        if (total) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&cout[shard * kCountStride], total);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (alive)
-                queue_push(qout, (size_t)shard * qout.cap + base + lane_rank(mask), ray, local, beta, rng, gpath);
-        }
-        PROF(if (COUNT) {
-            const unsigned long long te = __builtin_amdgcn_s_memtime();
-            uint32_t shade = (uint32_t)(te - ts0); // lanes without a ray still hold the chunk's start
-            for (int sh = 32; sh > 0; sh >>= 1) shade = min(shade, (uint32_t)__shfl_xor(shade, sh, 64));
-            cnt.p[8] += shade;
-            cnt.p[9] += te - tc0;
-            cnt.p[10]++;
-        })
-    }
+    const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
+    const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
+    uint8_t *mine = scratch + (size_t)w * kWaveScratchBytes;
+    BounceFeed feed{S, qin, qout, cout + shard * kCountStride, (size_t)shard * qin.cap, (size_t)shard * qout.cap,
+                    Blocks{(w / kShards) * 64, 0u, n, per_shard * 64}, bounce == last, seed, radiance,
+                    reinterpret_cast<float4 *>(mine), reinterpret_cast<float2 *>(mine + 2 * kParkSlots * 16),
+                    reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u};
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -813,25 +1143,27 @@ hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue 
     return hipGetLastError();
 }
 
+uint32_t bounce_waves(const LaunchShape &L) { return L.grid * ((L.lds_nodes ? 1024u : (uint32_t)kBlock) / 64u); }
+
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
-                         unsigned long long *counters, hipStream_t stream) {
+                         uint8_t *scratch, unsigned long long *counters, hipStream_t stream) {
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) {
         if (counters)
             RT_LAUNCH((k_bounce<true, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      counters);
+                      scratch, counters);
         else
             RT_LAUNCH((k_bounce<false, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      counters);
+                      scratch, counters);
     } else {
         if (counters)
             RT_LAUNCH((k_bounce<true, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      counters);
+                      scratch, counters);
         else
             RT_LAUNCH((k_bounce<false, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      counters);
+                      scratch, counters);
     }
     return hipGetLastError();
 }

@@ -54,9 +54,17 @@ hipError_t launch_generate_rays(const rt_camera &cam, uint32_t width, uint32_t s
                                 uint64_t first, uint32_t n, rt_ray *rays, hipStream_t stream);
 hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
                            uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream);
+// Per-wave memory of the bounce kernel: two lists of parked hit records (kParkSlots x 24
+// bytes each) and the lanes' traversal state while a shading batch runs (kSaveWords x 64
+// words).
+constexpr uint32_t kParkSlots = 128;
+constexpr uint32_t kSaveWords = 20;
+constexpr size_t kWaveScratchBytes = 2 * kParkSlots * 24 + kSaveWords * 64 * 4;
+// waves of the bounce grid (scratch must hold kWaveScratchBytes for each)
+uint32_t bounce_waves(const LaunchShape &L);
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
-                         unsigned long long *counters, hipStream_t stream);
+                         uint8_t *scratch, unsigned long long *counters, hipStream_t stream);
 hipError_t launch_resolve(const FrameDev &F, const float4 *radiance, uint32_t n_ranks, uint32_t s_count,
                           int finish, float4 *rgba, hipStream_t stream);
 
