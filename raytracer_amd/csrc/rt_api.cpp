@@ -364,7 +364,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
             break;
         default: { // RT_MEDIUM
             const rt_medium &m = s.media[pr.index];
-            rt::Medium o{m.boundary_kind, 0, m.xform, m.density};
+            rt::Medium o{m.boundary_kind, 0, m.xform, -1.0f / m.density};
             if (m.boundary_kind == RT_BOUNDARY_SPHERE) {
                 o.boundary_index = push_sphere(m.boundary_index);
                 lp.geom = spheres.back();

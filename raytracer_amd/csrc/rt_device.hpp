@@ -43,7 +43,7 @@ struct MSphere { // 32 B
 
 struct Medium { // 16 B
     uint32_t boundary_kind, boundary_index, xform;
-    float density;
+    float neg_inv_density; // -1.0f / density, divided on the host
 };
 
 struct ImageDev {
@@ -325,6 +325,34 @@ RT_DEV bool box_interval(v3 o, v3 d, const rt_box &b, float &tn_o, float &tf_o, 
     return true;
 }
 
+// Same for a ray whose reciprocal direction rd = 1.0f / d is already at hand (the traversal
+// loop computes exactly that value for its slab tests): three divisions fewer.
+RT_DEV bool box_interval_rd(v3 o, v3 d, v3 rd, const rt_box &b, float &tn_o, float &tf_o, int &fn_o, int &ff_o) {
+    float tn = -kInf, tf = kInf;
+    int fn = 0, ff = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float oi = comp(o, i), di = comp(d, i);
+        if (di == 0.0f) {
+            if (oi < b.lo[i] || oi > b.hi[i]) return false;
+            continue;
+        }
+        float inv = comp(rd, i);
+        float t0 = (b.lo[i] - oi) * inv;
+        float t1 = (b.hi[i] - oi) * inv;
+        int f0 = 2 * i, f1 = 2 * i + 1;
+        if (inv < 0.0f) {
+            float tt = t0; t0 = t1; t1 = tt;
+            int ft = f0; f0 = f1; f1 = ft;
+        }
+        if (t0 > tn) { tn = t0; fn = f0; }
+        if (t1 < tf) { tf = t1; ff = f1; }
+    }
+    if (tn > tf) return false;
+    tn_o = tn; tf_o = tf; fn_o = fn; ff_o = ff;
+    return true;
+}
+
 RT_DEV void rect_axes(uint32_t axis, int &A, int &B) {
     if (axis == 0) { A = 1; B = 2; }
     else if (axis == 1) { A = 0; B = 2; }
@@ -451,7 +479,7 @@ RT_DEV float medium_uniform(const Ray &ray, uint32_t prim) {
     h = hash32(prim ^ h);
     return (float)(h >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
-RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float4 sp, const Ray &ray,
+RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float4 sp, const Ray &ray, v3 rd,
                         float &t_out) {
     float t_in, t_out_b;
     v3 o, d;
@@ -459,6 +487,9 @@ RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float
         o = ray.o - mk(sp.x, sp.y, sp.z);
         d = ray.d;
         if (!sphere_roots(o, d, sp.w, t_in, t_out_b)) return false;
+    } else if (m.xform == 0) {
+        int fn, ff;
+        if (!box_interval_rd(ray.o, ray.d, rd, S.boxes[m.boundary_index], t_in, t_out_b, fn, ff)) return false;
     } else {
         int fn, ff;
         to_object(S, m.xform, ray, o, d);
@@ -469,8 +500,7 @@ RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float
     if (!(t_in < t_out_b)) return false;
     float len = length(ray.d);
     float inside = (t_out_b - t_in) * len;
-    float neg_inv_density = -1.0f / m.density;
-    float hit_dist = neg_inv_density * p_log(medium_uniform(ray, prim));
+    float hit_dist = m.neg_inv_density * p_log(medium_uniform(ray, prim));
     if (hit_dist > inside) return false;
     float t = t_in + hit_dist / len;
     if (!(t > 0.0f && t <= ray.t_max)) return false;
@@ -480,7 +510,8 @@ RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float
 
 // ---- one primitive ---------------------------------------------------------------------
 // aux: triangle barycentrics / box face.  Returns true for 0 < t <= ray.t_max.
-RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, float &t, float &a0,
+// rd = 1.0f / ray.d, as the traversal loop holds it.
+RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, v3 rd, float &t, float &a0,
                       float &a1, float &a2) {
     uint32_t kind = lp.kind & 0xffu;
     float t0, t1;
@@ -518,8 +549,12 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, flo
     case RT_BOX: {
         v3 o, d;
         int fn, ff;
-        to_object(S, lp.kind >> 16, ray, o, d);
-        if (!box_interval(o, d, S.boxes[lp.index], t0, t1, fn, ff)) return false;
+        if ((lp.kind >> 16) == 0) {
+            if (!box_interval_rd(ray.o, ray.d, rd, S.boxes[lp.index], t0, t1, fn, ff)) return false;
+        } else {
+            to_object(S, lp.kind >> 16, ray, o, d);
+            if (!box_interval(o, d, S.boxes[lp.index], t0, t1, fn, ff)) return false;
+        }
         float tt = t0;
         int face = fn;
         if (!(t0 > 0.0f)) { tt = t1; face = ff; }
@@ -529,7 +564,7 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, flo
         return true;
     }
     case RT_GSPHERE: return gsphere_test(S.gsph[lp.index], ray, t);
-    case RT_MEDIUM: return medium_test(S, lp.prim, S.media[lp.index], lp.geom, ray, t);
+    case RT_MEDIUM: return medium_test(S, lp.prim, S.media[lp.index], lp.geom, ray, rd, t);
     default: return false;
     }
 }

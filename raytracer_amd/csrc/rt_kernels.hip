@@ -396,12 +396,12 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                         Ray r2 = L.ray;
                         r2.o.x = opaque(r2.o.x);
                         float t2 = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-                        bool g = prim_test(S, lp, r2, t2, c0, c1, c2);
+                        bool g = prim_test(S, lp, r2, inv, t2, c0, c1, c2);
                         float sink = g ? t2 + c0 + c1 + c2 : 0.0f;
                         asm volatile("" ::"v"(sink));
                     }
 #endif
-                    const bool hit = prim_test(S, lp, L.ray, t, b0, b1, b2);
+                    const bool hit = prim_test(S, lp, L.ray, inv, t, b0, b1, b2);
                     if (hit) {
                         L.ray.t_max = t;
                         L.best = i | ((lp.kind & kRareShade) ? kBestRare : 0u);
@@ -947,17 +947,22 @@ struct BounceFeed {
         parked[0] += (uint32_t)__popcll(m0);
         parked[1] += (uint32_t)__popcll(m1);
         if (parked[0] >= 64 || parked[1] >= 64) {
-            // the traversing lanes' state leaves the registers while a batch is shaded
+            // The traversing lanes' state leaves the registers while a batch is shaded.  When no
+            // lane is traversing (small scenes: the rays of a wave finish together) there is
+            // nothing to keep: free lanes are reloaded or cleared below.
+            const bool any_busy = __ballot(T.cur != kNone) != 0;
             uint32_t *sv = save + lane;
-            sv[0 * 64] = __float_as_uint(L.ray.o.x); sv[1 * 64] = __float_as_uint(L.ray.o.y);
-            sv[2 * 64] = __float_as_uint(L.ray.o.z); sv[3 * 64] = __float_as_uint(L.ray.d.x);
-            sv[4 * 64] = __float_as_uint(L.ray.d.y); sv[5 * 64] = __float_as_uint(L.ray.d.z);
-            sv[6 * 64] = __float_as_uint(L.ray.t_max); sv[7 * 64] = __float_as_uint(L.ray.time);
-            sv[8 * 64] = L.best; sv[9 * 64] = __float_as_uint(L.a0);
-            sv[10 * 64] = __float_as_uint(L.a1); sv[11 * 64] = __float_as_uint(L.a2);
-            sv[12 * 64] = __float_as_uint(T.inv.x); sv[13 * 64] = __float_as_uint(T.inv.y);
-            sv[14 * 64] = __float_as_uint(T.inv.z); sv[15 * 64] = T.cur;
-            sv[16 * 64] = T.sp; sv[17 * 64] = entry;
+            if (any_busy) {
+                sv[0 * 64] = __float_as_uint(L.ray.o.x); sv[1 * 64] = __float_as_uint(L.ray.o.y);
+                sv[2 * 64] = __float_as_uint(L.ray.o.z); sv[3 * 64] = __float_as_uint(L.ray.d.x);
+                sv[4 * 64] = __float_as_uint(L.ray.d.y); sv[5 * 64] = __float_as_uint(L.ray.d.z);
+                sv[6 * 64] = __float_as_uint(L.ray.t_max); sv[7 * 64] = __float_as_uint(L.ray.time);
+                sv[8 * 64] = L.best; sv[9 * 64] = __float_as_uint(L.a0);
+                sv[10 * 64] = __float_as_uint(L.a1); sv[11 * 64] = __float_as_uint(L.a2);
+                sv[12 * 64] = __float_as_uint(T.inv.x); sv[13 * 64] = __float_as_uint(T.inv.y);
+                sv[14 * 64] = __float_as_uint(T.inv.z); sv[15 * 64] = T.cur;
+                sv[16 * 64] = T.sp; sv[17 * 64] = entry;
+            }
             // the compiler must really store and reload (no forwarding through registers),
             // and records parked by other lanes are read below
             asm volatile("" ::: "memory");
@@ -971,18 +976,27 @@ struct BounceFeed {
                 shade_batch<false>(kParkSlots + parked[1], 64);
             }
             asm volatile("" ::: "memory");
-            L.ray.o = mk(__uint_as_float(sv[0 * 64]), __uint_as_float(sv[1 * 64]), __uint_as_float(sv[2 * 64]));
-            L.ray.d = mk(__uint_as_float(sv[3 * 64]), __uint_as_float(sv[4 * 64]), __uint_as_float(sv[5 * 64]));
-            L.ray.t_max = __uint_as_float(sv[6 * 64]);
-            L.ray.time = __uint_as_float(sv[7 * 64]);
-            L.best = sv[8 * 64];
-            L.a0 = __uint_as_float(sv[9 * 64]);
-            L.a1 = __uint_as_float(sv[10 * 64]);
-            L.a2 = __uint_as_float(sv[11 * 64]);
-            T.inv = mk(__uint_as_float(sv[12 * 64]), __uint_as_float(sv[13 * 64]), __uint_as_float(sv[14 * 64]));
-            T.cur = sv[15 * 64];
-            T.sp = sv[16 * 64];
-            entry = sv[17 * 64];
+            if (any_busy) {
+                L.ray.o = mk(__uint_as_float(sv[0 * 64]), __uint_as_float(sv[1 * 64]), __uint_as_float(sv[2 * 64]));
+                L.ray.d = mk(__uint_as_float(sv[3 * 64]), __uint_as_float(sv[4 * 64]), __uint_as_float(sv[5 * 64]));
+                L.ray.t_max = __uint_as_float(sv[6 * 64]);
+                L.ray.time = __uint_as_float(sv[7 * 64]);
+                L.best = sv[8 * 64];
+                L.a0 = __uint_as_float(sv[9 * 64]);
+                L.a1 = __uint_as_float(sv[10 * 64]);
+                L.a2 = __uint_as_float(sv[11 * 64]);
+                T.inv = mk(__uint_as_float(sv[12 * 64]), __uint_as_float(sv[13 * 64]), __uint_as_float(sv[14 * 64]));
+                T.cur = sv[15 * 64];
+                T.sp = sv[16 * 64];
+                entry = sv[17 * 64];
+            } else {
+                L.ray.o = L.ray.d = T.inv = mk(0.0f, 0.0f, 0.0f);
+                L.ray.t_max = L.ray.time = L.a0 = L.a1 = L.a2 = 0.0f;
+                L.best = RT_MISS;
+                T.cur = kNone;
+                T.sp = 0;
+                entry = 0;
+            }
         }
         // next rays
         const uint32_t next = blocks.take(free);
