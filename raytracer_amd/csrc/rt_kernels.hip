@@ -139,6 +139,10 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #define RT_REFILL_LANES 32
 #endif
 constexpr uint32_t kRefillLanes = RT_REFILL_LANES;
+#ifndef RT_PRIMARY_REFILL_LANES
+#define RT_PRIMARY_REFILL_LANES 65
+#endif
+constexpr uint32_t kPrimaryRefillLanes = RT_PRIMARY_REFILL_LANES;
 
 constexpr uint32_t kBestRare = 0x80000000u;
 
@@ -218,7 +222,8 @@ struct Blocks {
 // received a ray (it may save the whole of Trav to memory and reload it), and
 // void finish(), called once when every ray of the wave has been consumed.
 template <bool ANY, bool COUNT, bool LDSN, class Feed>
-RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt) {
+RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt,
+                         const uint32_t refill_lanes = kRefillLanes) {
     constexpr int kStride = Shape<LDSN>::kThreads;
     using RefT = typename Shape<LDSN>::RefT;
     RefT *const s_ref = tv.ref;
@@ -280,7 +285,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
         {
             const bool busy = cur != kNone;
             const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
-            if (n_busy == 0 || (64u - n_busy >= kRefillLanes && feed.more())) {
+            if (n_busy == 0 || (64u - n_busy >= refill_lanes && feed.more())) {
                 const bool fresh = feed.turn(T, !busy);
                 if (fresh) { // bvh.rs:741-762: reciprocal direction, then the root's own box
                     inv = mk(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
@@ -320,7 +325,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             const uint32_t n_step = (uint32_t)__popcll(m_step);
             const uint32_t n_hold = (uint32_t)__popcll(__ballot(!stepping && cur != kNone));
             if (n_hold >= kLeafLanes) break;
-            if (can_refill && 64u - n_step - n_hold >= kRefillLanes) break;
+            if (can_refill && 64u - n_step - n_hold >= refill_lanes) break;
             PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
             if (stepping) {
                 bool need_pop = true;
@@ -1062,7 +1067,9 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) 
                     Blocks{(w / kShards) * 64, 0u, n, per_shard * 64}, bounce == last, seed, radiance,
                     reinterpret_cast<float4 *>(mine), reinterpret_cast<float2 *>(mine + 2 * kParkSlots * 16),
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u};
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt);
+    // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
+    // together and refilling in between only adds turns; scattered rays do not
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? kPrimaryRefillLanes : kRefillLanes);
     if (COUNT) flush_counters(cnt, counters);
 }
 
