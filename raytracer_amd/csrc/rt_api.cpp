@@ -441,6 +441,11 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     }
     if (force && !strcmp(force, "global")) lds_nodes = false;
     if (!lds_nodes) stack_lds = (uint32_t)std::min<size_t>(slots, lds_cu / 4 / (256 * 8));
+    // test hook: fewer LDS levels, so that the private part of the stack is exercised
+    if (const char *cap = getenv("RT355_STACK_LDS")) {
+        const uint32_t v = (uint32_t)atoi(cap);
+        if (v >= 1 && v < stack_lds) stack_lds = v;
+    }
     if (slots - stack_lds > rt::kSpillLevels) return fail(RT_ERR_LIMIT, "traversal stack too deep for this device");
     D.stack_lds = stack_lds;
     db.shape.slots = slots;

@@ -200,3 +200,58 @@ def test_full_size_properties(scene_cache):
             acc = acc + rgb[s]
         exp = acc / np.float32(spp)
         assert (a[pix // w, pix % w, :3] == exp).all(), pix
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nodes", ["lds", "global"])
+def test_streaming_paths(monkeypatch, nodes):
+    """Rays enter and leave a wave one by one: every batch size around the 64-entry blocks,
+    rays that miss the root box (lanes that never traverse), and both node sources."""
+    if nodes == "global":
+        monkeypatch.setenv("RT355_NODES", "global")
+    fr = mixed_scene(seed=9, n_each=60).freeze()
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    wb = o.world_bound()
+    for n in (2, 31, 32, 33, 127, 128, 129, 4095, 4097, 70001):
+        rays = random_rays(n, wb[:3], wb[3:], 100 + n)
+        # every third ray starts far away and points outwards: misses the root
+        rays["o"][::3] = wb[3:] + 50.0
+        rays["d"][::3] = np.abs(rays["d"][::3]) + 0.1
+        assert_hits_equal(g.intersect(rays), o.intersect(rays), "%s n=%d" % (nodes, n))
+        assert (g.does_intersect(rays) == o.occluded(rays)).all()
+    # a tree that is a single leaf (no interior record) and a single primitive
+    from raytracer_amd.scene import SceneData
+    s = SceneData()
+    s.lambertian((1, 1, 1))
+    s.add_sphere((0, 0, -3), 1.0)
+    fr1 = s.freeze()
+    g1, o1 = lib.Scene(fr1), orc.OracleScene(fr1)
+    rays = random_rays(1000, np.float32([-2, -2, -5]), np.float32([2, 2, 1]), 5)
+    assert_hits_equal(g1.intersect(rays), o1.intersect(rays), "single leaf")
+    img, st = g1.render(_cam(64, 48), lib.render_opts(64, 48, 3, 8, seed=3))
+    ref, rst = o1.render(_cam(64, 48), orc.render_opts(64, 48, 3, 8, seed=3))
+    assert img.tobytes() == ref.tobytes() and st.segments == rst.segments
+
+
+def _cam(w, h):
+    from raytracer_amd.scene import look_at, perspective_camera
+    return perspective_camera(w, h, 40.0, look_at((0.0, 0.0, 2.0), (0.0, 0.0, -3.0), (0.0, 1.0, 0.0)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nodes", ["lds", "global"])
+def test_stack_levels_beyond_lds(monkeypatch, nodes, scene_cache):
+    """With only two stack levels in LDS most pushes land in the per-lane private array."""
+    monkeypatch.setenv("RT355_STACK_LDS", "2")
+    if nodes == "global":
+        monkeypatch.setenv("RT355_NODES", "global")
+    name, cam, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    wb = o.world_bound()
+    rays = random_rays(50000, wb[:3], wb[3:], 77)
+    got, ref = g.intersect(rays), o.intersect(rays)
+    assert_hits_equal(got, ref, "spill " + nodes)
+    assert (g.does_intersect(rays) == o.occluded(rays)).all()
+    img, st = g.render(cam(96, 64), lib.render_opts(96, 64, 4, 20, seed=2))
+    ref_img, rst = o.render(cam(96, 64), orc.render_opts(96, 64, 4, 20, seed=2))
+    assert img.tobytes() == ref_img.tobytes() and st.segments == rst.segments
