@@ -162,7 +162,9 @@ def pbrt_test():
     distant light of the file is not modelled."""
     s = SceneData(background=(0.4, 0.45, 0.5))
     s.add_gsphere(identity(), 1.0, material=s.dielectric(1.5))
-    checks = s.add_texture(abi.RT_TEX_CHECKER_UV, a=s.solid((0.1, 0.1, 0.1)), b=s.solid((0.8, 0.8, 0.8)), scale=8.0)
+    # pbrt's checkerboard: cells with even floor(u) + floor(v) take tex1 (0.1), odd ones tex2 (0.8)
+    tex1, tex2 = s.solid((0.1, 0.1, 0.1)), s.solid((0.8, 0.8, 0.8))
+    checks = s.add_texture(abi.RT_TEX_CHECKER_UV, a=tex2, b=tex1, scale=8.0)
     s.add_mesh(translate((0.0, 0.0, -1.0)),
                [[-20, -20, 0], [20, -20, 0], [20, 20, 0], [-20, 20, 0]], [0, 1, 2, 0, 2, 3],
                uv=[[0, 0], [1, 0], [1, 1], [0, 1]], material=s.lambertian(texture=checks))
