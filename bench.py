@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--checksum", action="store_true", help="print a checksum of the final frame to stderr")
     args = ap.parse_args()
 
     import torch
@@ -86,9 +89,14 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     sd, camf = scenes.next_week()
     frozen = sd.freeze()
@@ -139,6 +147,9 @@ def main():
         dist.all_reduce(seg_sum, op=dist.ReduceOp.SUM)
         elapsed, segments = float(t_max.item()), float(seg_sum.item())
 
+    if rank == 0 and args.checksum:
+        import hashlib
+        print("frame sha256", hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest(), file=sys.stderr)
     if rank == 0:
         alg_bytes = algorithmic_bytes(counted)  # per frame, this rank's shard
         per_launch_ms = trace_ms / max(launches, 1)
