@@ -82,7 +82,9 @@ pub struct rt_scene_info { pub n_prims: u32, pub n_nodes: u32, pub max_depth: u3
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_camera { pub raster_to_camera: [f32; 16], pub camera_to_world: [f32; 12], pub lens_radius: f32, pub focal_distance: f32, pub shutter_open: f32, pub shutter_close: f32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
-pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub max_depth: u32, pub seed: u64, pub shard_index: u32, pub shard_count: u32, pub max_paths: u32, pub flags: u32 }
+pub struct rt_filter { pub kind: u32, pub radius: [f32; 2], pub a: f32, pub b: f32, pub _pad: u32 }
+#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub max_depth: u32, pub seed: u64, pub shard_index: u32, pub shard_count: u32, pub max_paths: u32, pub flags: u32, pub filter: rt_filter }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct rt_stats {
     pub paths: u64, pub segments: u64, pub nodes_visited: u64, pub prims_tested: [u64; 8],
@@ -108,6 +110,8 @@ extern "C" {
     pub fn rt_generate_rays(cam: *const rt_camera, opts: *const rt_render_opts, first_path: u64, n: usize, rays: *mut rt_ray, device: c_int) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, cam: *const rt_camera, opts: *const rt_render_opts, rgba_out: *mut f32, stats: *mut rt_stats, device: c_int) -> c_int;
     pub fn rt_render_dev(scene: *mut rt_scene, cam: *const rt_camera, opts: *const rt_render_opts, d_rgba_out: *mut f32, stats: *mut rt_stats, device: c_int, stream: *mut c_void) -> c_int;
+    pub fn rt_filter_table(filter: *const rt_filter, out: *mut f32) -> c_int;
+    pub fn rt_film_resolve_dev(d_rgba: *mut f32, width: u32, height: u32, device: c_int, stream: *mut c_void) -> c_int;
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_abi_sizes(out: *mut u32, cap: usize) -> c_int;
 }
@@ -121,7 +125,7 @@ pub fn check_layout() -> Result<(), String> {
         size_of::<rt_xform>(), size_of::<rt_medium>(), size_of::<rt_material>(), size_of::<rt_texture>(),
         size_of::<rt_image>(), size_of::<rt_scene_desc>(), size_of::<rt_build_opts>(),
         size_of::<rt_linear_node>(), size_of::<rt_scene_info>(), size_of::<rt_camera>(),
-        size_of::<rt_render_opts>(), size_of::<rt_stats>(),
+        size_of::<rt_filter>(), size_of::<rt_render_opts>(), size_of::<rt_stats>(),
     ];
     let mut theirs = [0u32; 64];
     let n = unsafe { rt_abi_sizes(theirs.as_mut_ptr(), theirs.len()) } as usize;

@@ -236,6 +236,30 @@ typedef struct rt_camera {
 
 #define RT_RENDER_COUNTERS 1u /* also count nodes visited / primitives tested    */
 #define RT_RENDER_TIMING 2u   /* bracket every trace launch with HIP events       */
+#define RT_RENDER_RAW_FILM 4u /* with a filter: leave {sum of w*L, sum of w} per pixel
+                                 (shards are summed before rt_film_resolve_dev)   */
+
+/* Reconstruction filters, colour/src/filters/{box,triangle,gaussian,mitchell,
+ * lanczos_sinc}.rs.  RT_FILTER_NONE keeps the legacy scenes' behaviour: a pixel
+ * is the plain mean of its own samples. */
+typedef enum rt_filter_kind {
+    RT_FILTER_NONE = 0,
+    RT_FILTER_BOX = 1,
+    RT_FILTER_TRIANGLE = 2,
+    RT_FILTER_GAUSSIAN = 3, /* a = alpha                                           */
+    RT_FILTER_MITCHELL = 4, /* a = B, b = C                                        */
+    RT_FILTER_LANCZOS = 5   /* a = tau                                             */
+} rt_filter_kind;
+
+typedef struct rt_filter {
+    uint32_t kind;
+    float radius[2]; /* in pixels, each at most RT_FILTER_MAX_RADIUS               */
+    float a, b;
+    uint32_t _pad;
+} rt_filter;
+
+#define RT_FILTER_MAX_RADIUS 8.0f
+#define RT_FILTER_TABLE_WIDTH 16 /* FILTER_TABLE_WIDTH, colour/src/film.rs:43      */
 
 typedef struct rt_render_opts {
     uint32_t width, height;
@@ -246,6 +270,7 @@ typedef struct rt_render_opts {
     uint32_t shard_count; /* t % shard_count == shard_index (0,1 = whole frame)   */
     uint32_t max_paths;   /* paths in flight per batch; 0 = library default       */
     uint32_t flags;
+    rt_filter filter;     /* Film's filter (film.rs:20); kind 0 = none             */
 } rt_render_opts;
 
 typedef struct rt_stats {
@@ -313,11 +338,25 @@ int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t 
 /* The render loop the reference's main never got (main/src/main.rs:55-60):
  * generate -> [intersect -> shade/scatter -> compact] x depth -> resolve.
  * rgba_out: width*height*4 floats, mean linear radiance, alpha 1 on owned
- * pixels, all 0 on pixels of other shards. */
+ * pixels, all 0 on pixels of other shards.
+ * With opts->filter.kind != 0 the samples go through the film instead
+ * (FilmTile::add_sample, film.rs:281-328): a sample at raster position p adds
+ * w * L and w to every pixel within the filter radius of p - 0.5, w from the
+ * filter table; a shard adds only its own tiles' samples, so with several
+ * shards pass RT_RENDER_RAW_FILM, sum the buffers and call rt_film_resolve_dev. */
 int rt_render(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts, float *rgba_out,
               rt_stats *stats, int device);
 int rt_render_dev(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts,
                   float *d_rgba_out, rt_stats *stats, int device, void *stream);
+
+/* The 16 x 16 table of filter values Film::new precomputes (film.rs:99-113):
+ * out[y * 16 + x] = eval((x + 0.5) * radius.x / 16, (y + 0.5) * radius.y / 16). */
+int rt_filter_table(const rt_filter *filter, float out[256]);
+
+/* Film::write_image's normalisation (film.rs:236-247) of a raw film
+ * {sum of w*L (rgb), sum of w}: rgb = max(0, sum * (1 / weight)) where the weight
+ * is not zero, alpha = 1.  In place, asynchronous on `stream`. */
+int rt_film_resolve_dev(float *d_rgba, uint32_t width, uint32_t height, int device, void *stream);
 
 /* Panic message analogue; valid until the next failing call on this thread. */
 const char *rt_last_error(void);

@@ -41,6 +41,10 @@ int orc_intersect_brute(const orc_scene *s, const rt_ray *rays, size_t n, rt_hit
 
 int orc_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t first_path,
                       size_t n, rt_ray *rays);
+/* Film::new's filter table (colour/src/film.rs:99-113) and write_image's
+ * normalisation (film.rs:236-247). */
+int orc_filter_table(const rt_filter *filter, float out[256]);
+void orc_film_resolve(float *rgba, uint32_t width, uint32_t height);
 int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
                float *rgba_out, rt_stats *stats, int threads);
 /* radiance of individual paths (3 floats each) for path ids [first, first+n) */

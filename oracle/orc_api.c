@@ -328,10 +328,156 @@ static int pixel_owned(const rt_render_opts *o, uint32_t px, uint32_t py) {
     return t % count == o->shard_index;
 }
 
+/* ---- film: colour/src/film.rs + the filters of colour/src/filters ------------------------------
+ * Deviations from the literal code, following pbrt-v3 which it transcribes: the table
+ * index uses the table WIDTH (16), not its length (film.rs:296-309 multiply by and clamp
+ * to 256, which indexes out of the 16 x 16 table); the pixel range of a sample is
+ * [ceil(d - r), floor(d + r)] (film.rs:287-288 truncate toward zero instead); Mitchell's
+ * outer cubic starts (-B - 6C) x^3 (mitchell.rs:33 multiplies B by 6C instead).  The
+ * RGB -> XYZ -> RGB round trip of FilmTile merge and write_image is left out (spectra
+ * are out of scope): sums are kept in RGB. */
+static float filter_eval(const rt_filter *f, float x, float y) {
+    float rx = f->radius[0], ry = f->radius[1];
+    switch (f->kind) {
+    case RT_FILTER_BOX: return 1.0f; /* box.rs:20-22 */
+    case RT_FILTER_TRIANGLE: { /* triangle.rs:18-20 */
+        float a = rx - fabsf(x), b = ry - fabsf(y);
+        return (a > 0.0f ? a : 0.0f) * (b > 0.0f ? b : 0.0f);
+    }
+    case RT_FILTER_GAUSSIAN: { /* gaussian.rs:15-32 */
+        float ex = expf(-f->a * rx * rx), ey = expf(-f->a * ry * ry);
+        float gx = expf(-f->a * x * x) - ex, gy = expf(-f->a * y * y) - ey;
+        return (gx > 0.0f ? gx : 0.0f) * (gy > 0.0f ? gy : 0.0f);
+    }
+    case RT_FILTER_MITCHELL: { /* mitchell.rs:17-50 */
+        float B = f->a, Cc = f->b, v[2] = {x * (1.0f / rx), y * (1.0f / ry)}, out[2];
+        for (int k = 0; k < 2; k++) {
+            float t = fabsf(2.0f * v[k]);
+            if (t > 1.0f)
+                out[k] = ((-B - 6.0f * Cc) * t * t * t + (6.0f * B + 30.0f * Cc) * t * t +
+                          (-12.0f * B - 48.0f * Cc) * t + (8.0f * B + 24.0f * Cc)) * (1.0f / 6.0f);
+            else
+                out[k] = ((12.0f - 9.0f * B - 6.0f * Cc) * t * t * t +
+                          (-18.0f + 12.0f * B + 6.0f * Cc) * t * t + (6.0f - 2.0f * B)) * (1.0f / 6.0f);
+        }
+        return out[0] * out[1];
+    }
+    case RT_FILTER_LANCZOS: { /* lanczos_sinc.rs:17-38 */
+        const float pi = 3.14159265358979323846f;
+        float v[2] = {fabsf(x), fabsf(y)}, r[2] = {rx, ry}, out[2];
+        for (int k = 0; k < 2; k++) {
+            if (v[k] > r[k]) { out[k] = 0.0f; continue; }
+            float a = v[k], b = v[k] / f->a;
+            float sa = a < 1e-5f ? 1.0f : sinf(pi * a) / (pi * a);
+            float sb = b < 1e-5f ? 1.0f : sinf(pi * b) / (pi * b);
+            out[k] = sa * sb;
+        }
+        return out[0] * out[1];
+    }
+    default: return 0.0f;
+    }
+}
+
+int orc_filter_table(const rt_filter *f, float out[256]) {
+    if (!f || !out || f->kind < RT_FILTER_BOX || f->kind > RT_FILTER_LANCZOS) return RT_ERR_INVALID;
+    if (!(f->radius[0] > 0.0f && f->radius[1] > 0.0f) || f->radius[0] > RT_FILTER_MAX_RADIUS ||
+        f->radius[1] > RT_FILTER_MAX_RADIUS)
+        return RT_ERR_INVALID;
+    for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++) /* film.rs:99-113 */
+            out[y * 16 + x] = filter_eval(f, ((float)x + 0.5f) * f->radius[0] / 16.0f,
+                                          ((float)y + 0.5f) * f->radius[1] / 16.0f);
+    return RT_OK;
+}
+
+void orc_film_resolve(float *rgba, uint32_t width, uint32_t height) { /* film.rs:236-247 */
+    for (size_t p = 0; p < (size_t)width * height; p++) {
+        float w = rgba[4 * p + 3];
+        if (w != 0.0f) {
+            float inv = 1.0f / w;
+            for (int c = 0; c < 3; c++) {
+                float v = rgba[4 * p + c] * inv;
+                rgba[4 * p + c] = v > 0.0f ? v : 0.0f;
+            }
+        }
+        rgba[4 * p + 3] = 1.0f;
+    }
+}
+
+/* FilmTile::add_sample (film.rs:281-328) in gather form: pixel (x, y) collects, for sample
+ * index s = 0 .. spp-1 in turn, the samples s of the pixels around it row by row.  The
+ * order of the additions is part of the definition (fp32 sums). */
+static int render_filtered(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts, float *rgba,
+                           rt_stats *stats, int threads) {
+    const uint32_t W = opts->width, H = opts->height, spp = opts->spp;
+    float table[256];
+    int rc = orc_filter_table(&opts->filter, table);
+    if (rc != RT_OK) return rc;
+    size_t npix = (size_t)W * H;
+    float *rad = (float *)calloc(npix * spp * 3, sizeof(float));
+    if (!rad) return RT_ERR_NOMEM;
+    uint64_t segments = 0, paths = 0, counters[9] = {0};
+    int want = (opts->flags & RT_RENDER_COUNTERS) != 0;
+    for (size_t p = 0; p < npix; p++) {
+        if (!pixel_owned(opts, (uint32_t)(p % W), (uint32_t)(p / W))) continue;
+        job j;
+        memset(&j, 0, sizeof j);
+        j.mode = 3; j.s = s; j.cam = cam; j.opts = opts; j.rad = rad + p * spp * 3;
+        j.first = (uint64_t)p * spp; j.want_counters = want;
+        run_jobs(&j, spp, 1);
+        segments += j.segments;
+        paths += spp;
+        for (int k = 0; k < 9; k++) counters[k] += j.counters[k];
+    }
+    (void)threads;
+    const float rx = opts->filter.radius[0], ry = opts->filter.radius[1];
+    const float inv_rx = 1.0f / rx, inv_ry = 1.0f / ry;
+    const int Rx = (int)ceilf(rx + 0.5f), Ry = (int)ceilf(ry + 0.5f);
+    for (uint32_t y = 0; y < H; y++)
+        for (uint32_t x = 0; x < W; x++) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t k = 0; k < spp; k++)
+                for (int qy = (int)y - Ry; qy <= (int)y + Ry; qy++)
+                    for (int qx = (int)x - Rx; qx <= (int)x + Rx; qx++) {
+                        if (qx < 0 || qy < 0 || qx >= (int)W || qy >= (int)H) continue;
+                        if (!pixel_owned(opts, (uint32_t)qx, (uint32_t)qy)) continue;
+                        uint64_t path = ((uint64_t)qy * W + (uint64_t)qx) * spp + k;
+                        orc_rng rng;
+                        orc_rng_seq(&rng, (opts->seed << 32) + path);
+                        float u1 = orc_rng_f(&rng), u2 = orc_rng_f(&rng);
+                        float dx = ((float)qx + u1) - 0.5f, dy = ((float)qy + u2) - 0.5f;
+                        float fxp = (float)x, fyp = (float)y;
+                        if (fxp < ceilf(dx - rx) || fxp > floorf(dx + rx)) continue;
+                        if (fyp < ceilf(dy - ry) || fyp > floorf(dy + ry)) continue;
+                        int ix = (int)floorf(fabsf((fxp - dx) * inv_rx * 16.0f));
+                        int iy = (int)floorf(fabsf((fyp - dy) * inv_ry * 16.0f));
+                        if (ix > 15) ix = 15;
+                        if (iy > 15) iy = 15;
+                        float w = table[iy * 16 + ix];
+                        const float *L = rad + path * 3;
+                        acc[0] += L[0] * w; acc[1] += L[1] * w; acc[2] += L[2] * w;
+                        acc[3] += w;
+                    }
+            float *o = rgba + 4 * ((size_t)y * W + x);
+            o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+        }
+    free(rad);
+    if (!(opts->flags & RT_RENDER_RAW_FILM)) orc_film_resolve(rgba, W, H);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->paths = paths;
+        stats->segments = segments;
+        stats->nodes_visited = counters[0];
+        for (int k = 0; k < 8; k++) stats->prims_tested[k] = counters[1 + k];
+    }
+    return RT_OK;
+}
+
 int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
                float *rgba, rt_stats *stats, int threads) {
     if (!s || !cam || !opts || !rgba || !opts->spp || !opts->width || !opts->height)
         return RT_ERR_INVALID;
+    if (opts->filter.kind != RT_FILTER_NONE) return render_filtered(s, cam, opts, rgba, stats, threads);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     size_t npix = (size_t)opts->width * opts->height;

@@ -22,7 +22,9 @@ RT_MAT_LAMBERTIAN, RT_MAT_METALLIC, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE, RT_TEX_NOISE, RT_TEX_CHECKER_UV = range(5)
 # rt_split_method == SplitMethod (shapes/src/bvh.rs:10-22)
 RT_SPLIT_SAH, RT_SPLIT_HLBVH, RT_SPLIT_MIDDLE, RT_SPLIT_EQUAL_COUNTS = range(4)
-RT_RENDER_COUNTERS, RT_RENDER_TIMING = 1, 2
+RT_RENDER_COUNTERS, RT_RENDER_TIMING, RT_RENDER_RAW_FILM = 1, 2, 4
+(RT_FILTER_NONE, RT_FILTER_BOX, RT_FILTER_TRIANGLE, RT_FILTER_GAUSSIAN, RT_FILTER_MITCHELL,
+ RT_FILTER_LANCZOS) = range(6)
 
 # numpy record layouts of the plain-data structs
 ray_dtype = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("t_max", "<f4"), ("time", "<f4")])
@@ -85,10 +87,16 @@ class rt_camera(C.Structure):
                 ("shutter_open", C.c_float), ("shutter_close", C.c_float)]
 
 
+class rt_filter(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("radius", C.c_float * 2), ("a", C.c_float), ("b", C.c_float),
+                ("_pad", C.c_uint32)]
+
+
 class rt_render_opts(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("max_depth", C.c_uint32), ("seed", C.c_uint64), ("shard_index", C.c_uint32),
-                ("shard_count", C.c_uint32), ("max_paths", C.c_uint32), ("flags", C.c_uint32)]
+                ("shard_count", C.c_uint32), ("max_paths", C.c_uint32), ("flags", C.c_uint32),
+                ("filter", rt_filter)]
 
 
 class rt_stats(C.Structure):
@@ -109,6 +117,7 @@ ABI_SIZES = [
     ("rt_image", C.sizeof(rt_image)), ("rt_scene_desc", C.sizeof(rt_scene_desc)),
     ("rt_build_opts", C.sizeof(rt_build_opts)), ("rt_linear_node", linear_node_dtype.itemsize),
     ("rt_scene_info", C.sizeof(rt_scene_info)), ("rt_camera", C.sizeof(rt_camera)),
+    ("rt_filter", C.sizeof(rt_filter)),
     ("rt_render_opts", C.sizeof(rt_render_opts)), ("rt_stats", C.sizeof(rt_stats)),
 ]
 
@@ -117,7 +126,8 @@ EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_world_bound", "rt_scene_get_info",
     "rt_scene_get_nodes", "rt_scene_get_prim_order", "rt_scene_upload", "rt_intersect",
     "rt_intersect_dev", "rt_intersect_count", "rt_occluded", "rt_occluded_dev",
-    "rt_generate_rays", "rt_render", "rt_render_dev", "rt_last_error", "rt_abi_sizes",
+    "rt_generate_rays", "rt_render", "rt_render_dev", "rt_filter_table", "rt_film_resolve_dev",
+    "rt_last_error", "rt_abi_sizes",
 ]
 
 
@@ -147,7 +157,9 @@ def declare(lib, prefix="rt_"):
         fn("occluded", i32, vp, vp, sz, vp, i32)
         fn("occluded_dev", i32, vp, vp, sz, vp, i32, vp)
         fn("generate_rays", i32, P(rt_camera), P(rt_render_opts), u64, sz, vp, i32)
+        fn("filter_table", i32, P(rt_filter), vp)
         fn("render", i32, vp, P(rt_camera), P(rt_render_opts), vp, P(rt_stats), i32)
         fn("render_dev", i32, vp, P(rt_camera), P(rt_render_opts), vp, P(rt_stats), i32, vp)
+        fn("film_resolve_dev", i32, vp, C.c_uint32, C.c_uint32, i32, vp)
         fn("abi_sizes", i32, P(C.c_uint32), sz)
     return lib

@@ -542,7 +542,7 @@ int rt_abi_sizes(uint32_t *out, size_t cap) {
                               sizeof(rt_medium),     sizeof(rt_material),    sizeof(rt_texture),
                               sizeof(rt_image),      sizeof(rt_scene_desc),  sizeof(rt_build_opts),
                               sizeof(rt_linear_node), sizeof(rt_scene_info), sizeof(rt_camera),
-                              sizeof(rt_render_opts), sizeof(rt_stats)};
+                              sizeof(rt_filter),     sizeof(rt_render_opts), sizeof(rt_stats)};
     size_t n = sizeof sizes / sizeof sizes[0];
     if (n > cap) n = cap;
     if (out) memcpy(out, sizes, n * sizeof(uint32_t));
@@ -756,6 +756,72 @@ int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t 
     return RT_OK;
 }
 
+namespace {
+
+// colour/src/filters/{box,triangle,gaussian,mitchell,lanczos_sinc}.rs, evaluated in fp32 with
+// the host's libm.  Mitchell's outer cubic starts (-B - 6C) x^3 as in pbrt (mitchell.rs:33
+// multiplies B by 6C).
+float filter_value(const rt_filter &f, float x, float y) {
+    const float rx = f.radius[0], ry = f.radius[1];
+    auto pos = [](float v) { return v > 0.0f ? v : 0.0f; };
+    switch (f.kind) {
+    case RT_FILTER_BOX: return 1.0f;
+    case RT_FILTER_TRIANGLE: return pos(rx - fabsf(x)) * pos(ry - fabsf(y));
+    case RT_FILTER_GAUSSIAN: {
+        auto g = [&](float d, float r) { return pos(expf(-f.a * d * d) - expf(-f.a * r * r)); };
+        return g(x, rx) * g(y, ry);
+    }
+    case RT_FILTER_MITCHELL: {
+        const float B = f.a, Cc = f.b;
+        auto m = [&](float v) {
+            const float t = fabsf(2.0f * v);
+            if (t > 1.0f)
+                return ((-B - 6.0f * Cc) * t * t * t + (6.0f * B + 30.0f * Cc) * t * t +
+                        (-12.0f * B - 48.0f * Cc) * t + (8.0f * B + 24.0f * Cc)) * (1.0f / 6.0f);
+            return ((12.0f - 9.0f * B - 6.0f * Cc) * t * t * t + (-18.0f + 12.0f * B + 6.0f * Cc) * t * t +
+                    (6.0f - 2.0f * B)) * (1.0f / 6.0f);
+        };
+        return m(x * (1.0f / rx)) * m(y * (1.0f / ry));
+    }
+    case RT_FILTER_LANCZOS: {
+        const float pi = 3.14159265358979323846f;
+        auto sinc = [&](float v) { return v < 1e-5f ? 1.0f : sinf(pi * v) / (pi * v); };
+        auto ws = [&](float v, float r) {
+            v = fabsf(v);
+            return v > r ? 0.0f : sinc(v) * sinc(v / f.a);
+        };
+        return ws(x, rx) * ws(y, ry);
+    }
+    default: return 0.0f;
+    }
+}
+
+} // namespace
+
+int rt_filter_table(const rt_filter *f, float out[256]) {
+    if (!f || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (f->kind < RT_FILTER_BOX || f->kind > RT_FILTER_LANCZOS) return fail(RT_ERR_INVALID, "unknown filter kind");
+    if (!(f->radius[0] > 0.0f && f->radius[1] > 0.0f) || f->radius[0] > RT_FILTER_MAX_RADIUS ||
+        f->radius[1] > RT_FILTER_MAX_RADIUS)
+        return fail(RT_ERR_INVALID, "filter radius must be in (0, %g]", (double)RT_FILTER_MAX_RADIUS);
+    for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++) // film.rs:99-113
+            out[y * 16 + x] = filter_value(*f, ((float)x + 0.5f) * f->radius[0] / 16.0f,
+                                           ((float)y + 0.5f) * f->radius[1] / 16.0f);
+    return RT_OK;
+}
+
+int rt_film_resolve_dev(float *d_rgba, uint32_t width, uint32_t height, int device, void *stream) {
+    if (!d_rgba) return fail(RT_ERR_INVALID, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(RT_ERR_NO_DEVICE, "device %d not available; librt355 has no CPU path", device);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(rt::launch_film_resolve(reinterpret_cast<float4 *>(d_rgba), (size_t)width * height,
+                                    static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
 int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, float *d_rgba, rt_stats *stats,
                   int device, void *stream) {
     DeviceBuffers *db;
@@ -769,6 +835,13 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     const uint32_t shard_count = o->shard_count ? o->shard_count : 1;
     if (o->shard_index >= shard_count) return fail(RT_ERR_INVALID, "shard index out of range");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rt::FilterDev film{};
+    const bool filtered = o->filter.kind != RT_FILTER_NONE;
+    if (filtered) {
+        if ((rc = rt_filter_table(&o->filter, film.w)) != RT_OK) return rc;
+        film.rx = o->filter.radius[0];
+        film.ry = o->filter.radius[1];
+    }
     std::lock_guard<std::mutex> g(db->render_lock);
 
     rt::FrameDev F{o->width, o->height, o->spp, (o->width + 31) / 32, o->shard_index, shard_count, o->seed};
@@ -825,8 +898,14 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
             launches++;
         }
-        HIP_TRY(rt::launch_resolve(F, db->radiance, n_ranks, sc, s0 + sc >= o->spp ? 1 : 0,
-                                   reinterpret_cast<float4 *>(d_rgba), st));
+        if (filtered) {
+            HIP_TRY(rt::launch_film(F, film, db->radiance, s0, sc, reinterpret_cast<float4 *>(d_rgba), st));
+            if (s0 + sc >= o->spp && !(o->flags & RT_RENDER_RAW_FILM))
+                HIP_TRY(rt::launch_film_resolve(reinterpret_cast<float4 *>(d_rgba), (size_t)o->width * o->height, st));
+        } else {
+            HIP_TRY(rt::launch_resolve(F, db->radiance, n_ranks, sc, s0 + sc >= o->spp ? 1 : 0,
+                                       reinterpret_cast<float4 *>(d_rgba), st));
+        }
         // queue sizes of this batch = ray segments traced per bounce
         HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, counts.size() * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));

@@ -1098,6 +1098,63 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev F, const float4 *ra
     rgba[pix] = acc;
 }
 
+// FilmTile::add_sample (film.rs:281-328) in gather form: one thread per image pixel adds,
+// for each sample index of the batch in turn, the samples of the pixels around it row by
+// row (those this shard traced), weighted by the filter table.  Sample positions are the
+// first two draws of the path's generator, regenerated here.  The running sums
+// {sum w*L, sum w} stay in rgba between batches; the order of the additions is fixed, so
+// the result does not depend on how the samples are batched.
+__global__ __launch_bounds__(kBlock) void k_film(FrameDev F, FilterDev T, const float4 *radiance, uint32_t s0,
+                                                 uint32_t s_count, float4 *rgba) {
+    const size_t pix = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= (size_t)F.width * F.height) return;
+    const int x = (int)(pix % F.width), y = (int)(pix / F.width);
+    const float inv_rx = 1.0f / T.rx, inv_ry = 1.0f / T.ry;
+    const int Rx = (int)ceilf(T.rx + 0.5f), Ry = (int)ceilf(T.ry + 0.5f);
+    const float fxp = (float)x, fyp = (float)y;
+    float4 acc = rgba[pix];
+    for (uint32_t k = 0; k < s_count; k++)
+        for (int qy = y - Ry; qy <= y + Ry; qy++)
+            for (int qx = x - Rx; qx <= x + Rx; qx++) {
+                if (qx < 0 || qy < 0 || qx >= (int)F.width || qy >= (int)F.height) continue;
+                const uint32_t tile = ((uint32_t)qy >> 5) * F.tiles_x + ((uint32_t)qx >> 5);
+                if (tile % F.shard_count != F.shard_index) continue;
+                const uint32_t rank = (tile / F.shard_count) * 1024u + (((uint32_t)qy & 31u) << 5) + ((uint32_t)qx & 31u);
+                const uint64_t path = ((uint64_t)qy * F.width + (uint64_t)qx) * F.spp + (s0 + k);
+                Rng rng;
+                rng_seq(rng, (F.seed << 32) + path);
+                const float u1 = rng_f(rng), u2 = rng_f(rng);
+                const float dx = ((float)qx + u1) - 0.5f, dy = ((float)qy + u2) - 0.5f;
+                if (fxp < ceilf(dx - T.rx) || fxp > floorf(dx + T.rx)) continue;
+                if (fyp < ceilf(dy - T.ry) || fyp > floorf(dy + T.ry)) continue;
+                int ix = (int)floorf(fabsf((fxp - dx) * inv_rx * 16.0f));
+                int iy = (int)floorf(fabsf((fyp - dy) * inv_ry * 16.0f));
+                if (ix > 15) ix = 15;
+                if (iy > 15) iy = 15;
+                const float w = T.w[iy * 16 + ix];
+                const float4 L = radiance[(size_t)rank * s_count + k];
+                acc.x += L.x * w;
+                acc.y += L.y * w;
+                acc.z += L.z * w;
+                acc.w += w;
+            }
+    rgba[pix] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_film_resolve(float4 *rgba, size_t n) { // film.rs:236-247
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 v = rgba[i];
+    if (v.w != 0.0f) {
+        const float inv = 1.0f / v.w;
+        v.x = sel_max(v.x * inv, 0.0f);
+        v.y = sel_max(v.y * inv, 0.0f);
+        v.z = sel_max(v.z * inv, 0.0f);
+    }
+    v.w = 1.0f;
+    rgba[i] = v;
+}
+
 // ---- host-side launchers ------------------------------------------------------------------------------
 // dynamic LDS: the LDS part of the stacks (child reference + entry distance per level and
 // lane), preceded by the interior records for the LDS-resident shape
@@ -1186,6 +1243,19 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
             RT_LAUNCH((k_bounce<false, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
                       scratch, counters);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_film(const FrameDev &F, const FilterDev &T, const float4 *radiance, uint32_t s0,
+                       uint32_t s_count, float4 *rgba, hipStream_t stream) {
+    const size_t n = (size_t)F.width * F.height;
+    hipLaunchKernelGGL(k_film, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, F, T, radiance,
+                       s0, s_count, rgba);
+    return hipGetLastError();
+}
+
+hipError_t launch_film_resolve(float4 *rgba, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rgba, n);
     return hipGetLastError();
 }
 

@@ -65,6 +65,16 @@ uint32_t bounce_waves(const LaunchShape &L);
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
                          uint8_t *scratch, unsigned long long *counters, hipStream_t stream);
+// Film::new's table of filter values (film.rs:99-113), passed to the film kernel by value.
+struct FilterDev {
+    float w[256];
+    float rx, ry;
+};
+// FilmTile::add_sample (film.rs:281-328) for one batch of samples, gathered per pixel.
+hipError_t launch_film(const FrameDev &F, const FilterDev &T, const float4 *radiance, uint32_t s0,
+                       uint32_t s_count, float4 *rgba, hipStream_t stream);
+// Film::write_image's normalisation (film.rs:236-247), in place.
+hipError_t launch_film_resolve(float4 *rgba, size_t n_pixels, hipStream_t stream);
 hipError_t launch_resolve(const FrameDev &F, const float4 *radiance, uint32_t n_ranks, uint32_t s_count,
                           int finish, float4 *rgba, hipStream_t stream);
 

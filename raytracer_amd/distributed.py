@@ -21,12 +21,19 @@ def tiles_of(width, height, rank, world):
     return list(range(rank, tiles_x * tiles_y, world))
 
 
-def render_frame(render_shard, framebuffer, rank, world, dist=None):
+def render_frame(render_shard, framebuffer, rank, world, dist=None, resolve=None):
     """``render_shard(shard_index, shard_count, framebuffer)`` fills this rank's
     tiles (and zeroes the rest); with world > 1 the buffers are summed onto
     rank 0 through ``dist`` (torch.distributed, backend nccl = RCCL on GPUs,
-    gloo in CPU tests).  Returns what ``render_shard`` returned."""
+    gloo in CPU tests).  Returns what ``render_shard`` returned.
+
+    With a reconstruction filter a sample also weighs on pixels of other ranks'
+    tiles: ``render_shard`` must then leave a raw film (RT_RENDER_RAW_FILM:
+    sums of w*L and of w, which add across ranks) and ``resolve(framebuffer)``
+    normalises the summed film on rank 0 (rt_film_resolve_dev)."""
     out = render_shard(rank, world, framebuffer)
     if world > 1:
         dist.reduce(framebuffer, dst=0, op=dist.ReduceOp.SUM)
+    if resolve is not None and rank == 0:
+        resolve(framebuffer)
     return out

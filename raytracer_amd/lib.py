@@ -48,9 +48,29 @@ def check(rc):
     return rc
 
 
-def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0):
+def make_filter(kind=abi.RT_FILTER_NONE, radius=(0.5, 0.5), a=0.0, b=0.0):
+    """rt_filter: Box / Triangle / Gaussian(alpha) / Mitchell(B, C) / LanczosSinc(tau) ::new."""
+    f = abi.rt_filter()
+    f.kind = kind
+    f.radius[:] = radius
+    f.a, f.b = a, b
+    return f
+
+
+def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0, filter=None):
     return abi.rt_render_opts(width, height, spp, max_depth, seed, shard[0], shard[1], max_paths,
-                              flags)
+                              flags, filter if filter is not None else abi.rt_filter())
+
+
+def filter_table(filt):
+    """Film::new's 16 x 16 table of filter values (film.rs:99-113)."""
+    out = np.zeros(256, dtype=np.float32)
+    check(load().rt_filter_table(C.byref(filt), out.ctypes.data))
+    return out.reshape(16, 16)
+
+
+def film_resolve_dev(rgba_ptr, width, height, device=0, stream=None):
+    check(load().rt_film_resolve_dev(rgba_ptr, width, height, device, stream))
 
 
 class Scene:

@@ -36,6 +36,10 @@ def lib():
         L.orc_generate_rays.argtypes = [P(abi.rt_camera), P(abi.rt_render_opts), u64, sz, vp]
         L.orc_render.restype = i32
         L.orc_render.argtypes = [vp, P(abi.rt_camera), P(abi.rt_render_opts), vp, P(abi.rt_stats), i32]
+        L.orc_filter_table.restype = i32
+        L.orc_filter_table.argtypes = [P(abi.rt_filter), vp]
+        L.orc_film_resolve.restype = None
+        L.orc_film_resolve.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.orc_path_radiance.restype = i32
         L.orc_path_radiance.argtypes = [vp, P(abi.rt_camera), P(abi.rt_render_opts), u64, sz, vp, vp]
         L.orc_bounds_union.argtypes = [vp, vp, vp]
@@ -67,9 +71,22 @@ def make_opts(max_prims=4, split=abi.RT_SPLIT_SAH):
     return abi.rt_build_opts(max_prims, split)
 
 
-def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0):
+def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0, filter=None):
     return abi.rt_render_opts(width, height, spp, max_depth, seed, shard[0], shard[1], max_paths,
-                              flags)
+                              flags, filter if filter is not None else abi.rt_filter())
+
+
+def filter_table(filt):
+    out = np.zeros(256, dtype=np.float32)
+    _check(lib().orc_filter_table(C.byref(filt), out.ctypes.data))
+    return out.reshape(16, 16)
+
+
+def film_resolve(rgba):
+    """In place: Film::write_image's normalisation of a raw film."""
+    h, w = rgba.shape[:2]
+    lib().orc_film_resolve(rgba.ctypes.data, w, h)
+    return rgba
 
 
 class OracleScene:
