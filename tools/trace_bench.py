@@ -25,9 +25,10 @@ def main():
     info = scene.info()
     n = 1 << log2n
     w = 4096
-    h = n // w
+    h = min(n // w, 4096)
+    spp = n // (w * h)  # beyond 2^24 rays: more samples per pixel of a 4096 x 4096 frame
     cam = camf(w, h)
-    opts = lib.render_opts(w, h, 1, seed=0)
+    opts = lib.render_opts(w, h, spp, seed=0)
     L = lib.load()
     import ctypes as C
     d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
