@@ -15,7 +15,7 @@ fn main() {
     let status = Command::new(hipcc)
         .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"])
         // part of the numerical contract: multiply-adds round twice
-        .args(["-ffp-contract=off", "-fno-fast-math"])
+        .args(["-ffp-contract=off", "-fno-fast-math", "-pthread"])
         .arg("-I").arg(root.join("include"))
         .arg("-I").arg(&csrc)
         .args(["-x", "hip"])

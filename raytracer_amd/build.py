@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "librt355.so")
 SOURCES = ["rt_kernels.hip", "rt_api.cpp", "rt_bvh.cpp"]
 HEADERS = ["rt_device.hpp", "rt_kernels.hpp", "rt_bvh.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function"]
 
 
 def stale():

@@ -12,7 +12,14 @@
 
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <stdio.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace rt {
 namespace {
@@ -103,7 +110,11 @@ class Builder {
 
     int32_t run() {
         uint32_t n = (uint32_t)info_.size();
-        return method_ == RT_SPLIT_HLBVH ? hlbvh(n) : top_down(0, n);
+        if (method_ == RT_SPLIT_HLBVH) return hlbvh(n);
+        int32_t root = parallel_top_down(n);
+        order_.resize(n); // leaves cover info_ left to right: the final order of info_ is the leaf order
+        for (uint32_t i = 0; i < n; i++) order_[i] = info_[i].prim;
+        return root;
     }
 
     std::vector<BuildNode> pool_;
@@ -146,27 +157,76 @@ class Builder {
         return n / 2;
     }
 
-    int32_t alloc() {
-        pool_.emplace_back();
-        return (int32_t)pool_.size() - 1;
-    }
+    using Pool = std::vector<BuildNode>;
 
-    int32_t leaf(uint32_t start, uint32_t end, const Aabb &box) { // bvh.rs:241-258, range start..start+n
-        int32_t id = alloc();
-        pool_[id].first = (uint32_t)order_.size();
-        pool_[id].count = end - start;
-        pool_[id].box = box;
-        for (uint32_t i = start; i < end; i++) order_.push_back(info_[i].prim);
+    static int32_t alloc(Pool &pool) {
+        pool.emplace_back();
+        return (int32_t)pool.size() - 1;
+    }
+    int32_t alloc() { return alloc(pool_); }
+
+    // bvh.rs:241-258, range start..start+n; the leaf's primitives are info_[start..end)
+    static int32_t leaf(Pool &pool, uint32_t start, uint32_t end, const Aabb &box) {
+        int32_t id = alloc(pool);
+        pool[id].first = start;
+        pool[id].count = end - start;
+        pool[id].box = box;
         return id;
     }
 
-    int32_t interior(int axis, int32_t c0, int32_t c1) {
-        int32_t id = alloc();
-        pool_[id].child[0] = c0;
-        pool_[id].child[1] = c1;
-        pool_[id].axis = axis;
-        pool_[id].box = merge(pool_[c0].box, pool_[c1].box);
+    static int32_t interior(Pool &pool, int axis, int32_t c0, int32_t c1) {
+        int32_t id = alloc(pool);
+        pool[id].child[0] = c0;
+        pool[id].child[1] = c1;
+        pool[id].axis = axis;
+        pool[id].box = merge(pool[c0].box, pool[c1].box);
         return id;
+    }
+    int32_t interior(int axis, int32_t c0, int32_t c1) { return interior(pool_, axis, c0, c1); }
+
+    // Subtrees of at most grain_ primitives found while the top of the tree is built are put
+    // aside (a placeholder node holds their box) and built by worker threads into pools of
+    // their own, which are then spliced in.  Subtrees share nothing but disjoint ranges of
+    // info_, and node numbers are assigned later by the pre-order flattening, so the tree does
+    // not depend on the number of threads.
+    struct Task {
+        uint32_t start, end;
+        int32_t node;
+    };
+
+    int32_t parallel_top_down(uint32_t n) {
+        unsigned threads = std::thread::hardware_concurrency();
+        if (const char *e = getenv("RT355_BUILD_THREADS")) threads = (unsigned)atoi(e);
+        else if (const char *e2 = getenv("OMP_NUM_THREADS")) threads = std::min(threads, (unsigned)atoi(e2));
+        threads = std::max(1u, std::min(threads, 64u));
+        if (threads == 1 || n < (1u << 16)) return top_down(pool_, 0, n, nullptr);
+        grain_ = std::max(4096u, n / (threads * 8));
+        std::vector<Task> tasks;
+        int32_t root = top_down(pool_, 0, n, &tasks);
+        std::vector<Pool> pools(tasks.size());
+        std::vector<int32_t> roots(tasks.size(), -1);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t t = next++; t < tasks.size(); t = next++)
+                roots[t] = top_down(pools[t], tasks[t].start, tasks[t].end, nullptr);
+        };
+        std::vector<std::thread> pool_threads;
+        for (unsigned t = 1; t < threads; t++) pool_threads.emplace_back(work);
+        work();
+        for (auto &t : pool_threads) t.join();
+        for (size_t t = 0; t < tasks.size(); t++) {
+            const int32_t base = (int32_t)pool_.size();
+            for (BuildNode nd : pools[t]) {
+                if (nd.child[0] >= 0) {
+                    nd.child[0] += base;
+                    nd.child[1] += base;
+                }
+                pool_.push_back(nd);
+            }
+            pool_[tasks[t].node] = pool_[base + roots[t]];
+            Pool().swap(pools[t]);
+        }
+        return root;
     }
 
     // sah(), bvh.rs:300-382.  Returns the split position or -1 for a leaf.
@@ -195,16 +255,23 @@ class Builder {
         return -1;
     }
 
-    int32_t top_down(uint32_t start, uint32_t end) { // recursive_build, bvh.rs:154-238
+    // recursive_build, bvh.rs:154-238
+    int32_t top_down(Pool &pool, uint32_t start, uint32_t end, std::vector<Task> *defer) {
         PrimInfo *a = info_.data() + start;
         uint32_t n = end - start;
         Aabb box = empty_box();
         for (uint32_t i = 0; i < n; i++) box = merge(box, a[i].box);
-        if (n == 1) return leaf(start, end, box);
+        if (n == 1) return leaf(pool, start, end, box);
+        if (defer && n <= grain_) {
+            int32_t id = alloc(pool);
+            pool[id].box = box;
+            defer->push_back(Task{start, end, id});
+            return id;
+        }
         Aabb cb = empty_box();
         for (uint32_t i = 0; i < n; i++) cb = merge_point(cb, a[i].centroid);
         int dim = longest_axis(cb);
-        if (cb.hi[dim] == cb.lo[dim]) return leaf(start, end, box);
+        if (cb.hi[dim] == cb.lo[dim]) return leaf(pool, start, end, box);
         int64_t mid;
         if (method_ == RT_SPLIT_MIDDLE) { // bvh.rs:261-276
             float pmid = (cb.lo[dim] + cb.hi[dim]) / 2.0f;
@@ -214,12 +281,12 @@ class Builder {
             mid = halves(a, n, dim);
         } else {
             mid = sah(a, n, cb, dim, box);
-            if (mid < 0) return leaf(start, end, box);
+            if (mid < 0) return leaf(pool, start, end, box);
             if (mid == 0 || mid == (int64_t)n) mid = halves(a, n, dim);
         }
-        int32_t c0 = top_down(start, start + (uint32_t)mid);
-        int32_t c1 = top_down(start + (uint32_t)mid, end);
-        return interior(dim, c0, c1);
+        int32_t c0 = top_down(pool, start, start + (uint32_t)mid, defer);
+        int32_t c1 = top_down(pool, start + (uint32_t)mid, end, defer);
+        return interior(pool, dim, c0, c1);
     }
 
     // ---- HLBVH ----
@@ -347,6 +414,7 @@ class Builder {
 
     std::vector<PrimInfo> info_;
     uint32_t max_prims_, method_;
+    uint32_t grain_ = 0;
 };
 
 uint32_t flatten(const std::vector<BuildNode> &pool, int32_t id, std::vector<rt_linear_node> &out) {
@@ -394,8 +462,14 @@ int build_tree(const std::vector<Aabb> &bounds, uint32_t max_prims_in_node, uint
     if (bounds.empty()) return RT_OK;
     uint32_t max_prims = max_prims_in_node ? max_prims_in_node : 4;
     if (max_prims > 255) max_prims = 255; // bvh.rs:114
+    const bool timing = getenv("RT355_BUILD_TIMING") != nullptr; // phase times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now();
     Builder b(bounds, max_prims, split_method);
+    auto t1 = now();
     int32_t root = b.run();
+    auto t2 = now();
     for (const BuildNode &n : b.pool_)
         if (n.child[0] < 0 && n.count > 65535) {
             err = "leaf with more than 65535 primitives";
@@ -404,7 +478,11 @@ int build_tree(const std::vector<Aabb> &bounds, uint32_t max_prims_in_node, uint
     out.nodes.reserve(b.pool_.size());
     flatten(b.pool_, root, out.nodes);
     out.order = std::move(b.order_);
+    auto t3 = now();
     out.max_depth = tree_depth(out.nodes);
+    if (timing)
+        fprintf(stderr, "rt355 build: info %.0f ms, tree %.0f ms, flatten %.0f ms, depth %.0f ms\n", ms(t0, t1),
+                ms(t1, t2), ms(t2, t3), ms(t3, now()));
     if (out.max_depth > 64) { // nodes_to_visit = [0; 64], bvh.rs:753
         err = "tree needs " + std::to_string(out.max_depth) + " stack entries, the traversal stack holds 64";
         return RT_ERR_DEPTH;
