@@ -20,6 +20,7 @@ fn main() {
         .arg("-I").arg(&csrc)
         .args(["-x", "hip"])
         .arg(csrc.join("rt_kernels.hip"))
+        .arg(csrc.join("rt_build_gpu.hip"))
         .arg(csrc.join("rt_api.cpp"))
         .arg(csrc.join("rt_bvh.cpp"))
         .arg("-o").arg(out.join("librt355.so"))
@@ -28,7 +29,7 @@ fn main() {
     assert!(status.success(), "hipcc failed");
     println!("cargo:rustc-link-search=native={}", out.display());
     println!("cargo:rustc-link-lib=dylib=rt355");
-    for f in ["rt_kernels.hip", "rt_api.cpp", "rt_bvh.cpp", "rt_device.hpp", "rt_kernels.hpp", "rt_bvh.hpp"] {
+    for f in ["rt_kernels.hip", "rt_build_gpu.hip", "rt_api.cpp", "rt_bvh.cpp", "rt_device.hpp", "rt_kernels.hpp", "rt_bvh.hpp"] {
         println!("cargo:rerun-if-changed={}", csrc.join(f).display());
     }
     println!("cargo:rerun-if-changed={}", root.join("include/rt355.h").display());

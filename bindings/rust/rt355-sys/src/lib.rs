@@ -74,7 +74,7 @@ pub struct rt_scene_desc {
 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
-pub struct rt_build_opts { pub max_prims_in_node: u32, pub split_method: u32 }
+pub struct rt_build_opts { pub max_prims_in_node: u32, pub split_method: u32, pub flags: u32, pub device: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_linear_node { pub lo: [f32; 3], pub hi: [f32; 3], pub child_offset: u32, pub primitive_count: u16, pub axis: u8, pub _pad: u8 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]

@@ -199,9 +199,13 @@ typedef enum rt_split_method {
     RT_SPLIT_EQUAL_COUNTS = 3
 } rt_split_method;
 
+#define RT_BUILD_ON_DEVICE 1u /* HLBVH only: Morton codes, sort and treelets on the GPU */
+
 typedef struct rt_build_opts {
     uint32_t max_prims_in_node; /* clamped to 255 (bvh.rs:114)                    */
     uint32_t split_method;
+    uint32_t flags;             /* RT_BUILD_*                                     */
+    uint32_t device;            /* HIP device of a RT_BUILD_ON_DEVICE build       */
 } rt_build_opts;
 
 /* LinearBVHNode, shapes/src/bvh.rs:79-101, exactly 32 bytes. */
@@ -291,7 +295,10 @@ typedef struct rt_scene rt_scene;
 /* BVH::new (bvh.rs:108-121) + Sphere::new (sphere.rs:28-47) +
  * TriangleMesh::new / Triangle::from_mesh (triangle_mesh.rs:20-38,
  * triangle.rs:39-62): builds the tree on the host, flattens it
- * (bvh.rs:661-691).  Nothing is uploaded until a device is first used. */
+ * (bvh.rs:661-691).  Nothing is uploaded until a device is first used.
+ * With RT_BUILD_ON_DEVICE (split method HLBVH) the Morton codes, the radix sort
+ * and the treelets of hlbvh_build (bvh.rs:385-538) are computed on opts->device;
+ * the tree is the same, node for node. */
 int rt_scene_create(const rt_scene_desc *desc, const rt_build_opts *opts, rt_scene **out);
 
 /* Drop for BVH. Frees host and device memory on every device used. */

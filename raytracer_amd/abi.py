@@ -73,7 +73,11 @@ class rt_scene_desc(C.Structure):
 
 
 class rt_build_opts(C.Structure):
-    _fields_ = [("max_prims_in_node", C.c_uint32), ("split_method", C.c_uint32)]
+    _fields_ = [("max_prims_in_node", C.c_uint32), ("split_method", C.c_uint32), ("flags", C.c_uint32),
+                ("device", C.c_uint32)]
+
+
+RT_BUILD_ON_DEVICE = 1
 
 
 class rt_scene_info(C.Structure):

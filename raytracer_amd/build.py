@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt355.so")
-SOURCES = ["rt_kernels.hip", "rt_api.cpp", "rt_bvh.cpp"]
+SOURCES = ["rt_kernels.hip", "rt_build_gpu.hip", "rt_api.cpp", "rt_bvh.cpp"]
 HEADERS = ["rt_device.hpp", "rt_kernels.hpp", "rt_bvh.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function"]

@@ -580,8 +580,15 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
         std::vector<Aabb> bounds(s->prims.size());
         for (size_t i = 0; i < bounds.size(); i++) bounds[i] = prim_bounds(*s, s->prims[i]);
         std::string err;
-        int rc = rt::build_tree(bounds, opts ? opts->max_prims_in_node : 4,
+        int rc;
+        if (opts && (opts->flags & RT_BUILD_ON_DEVICE)) {
+            if (opts->split_method != RT_SPLIT_HLBVH)
+                return fail(RT_ERR_INVALID, "only the HLBVH split method builds on the device");
+            rc = rt::build_tree_hlbvh_device(bounds, opts->max_prims_in_node, (int)opts->device, s->tree, err);
+        } else {
+            rc = rt::build_tree(bounds, opts ? opts->max_prims_in_node : 4,
                                 opts ? opts->split_method : (uint32_t)RT_SPLIT_SAH, s->tree, err);
+        }
         if (rc != RT_OK) return fail(rc, "%s", err.c_str());
         s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *out = s.release();

@@ -1,0 +1,346 @@
+// rt_build_gpu.hip -- HLBVH construction on the GPU (hlbvh_build, shapes/src/bvh.rs:385-449):
+// Morton codes (:396-406, morton_encode3 :903-919), the radix sort (:923-966, here
+// rocPRIM's stable LSD sort: a stable sort on the 30-bit code has one possible result),
+// and the treelets (emit_lvbh :452-538).  Only the small SAH tree above the at most 4096
+// treelets (build_upper_sah :541-658) runs on the host.  The output is the host builder's
+// tree node for node: boxes are unions (min / max, exact in any order), splits are found
+// with the same binary search, and node numbers are those of the pre-order flattening
+// (flatten_tree :661-691), assigned here from subtree sizes.
+//
+// emit_lvbh is a recursion; on the GPU its call tree is built breadth first.  A node is a
+// range [lo, hi) of the sorted primitives and the bit to test next; one thread per node of
+// the current level finds the split and appends two children (consecutive numbers from an
+// atomic counter, so a level is a contiguous block of nodes).  Then one pass per level
+// upwards computes boxes and subtree sizes, one pass per level downwards the pre-order
+// indices, and a last pass writes the 32-byte linear nodes.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+
+#include "rt_bvh.hpp"
+
+namespace rt {
+namespace {
+
+struct GNode {
+    uint32_t lo, hi;   // range of sorted primitives
+    int32_t bit;       // in: first bit to test; out: the bit this node splits at
+    int32_t child[2];  // -1: leaf
+    uint32_t treelet;
+    uint32_t size;     // nodes in the subtree
+    uint32_t index;    // pre-order index inside the treelet
+    Aabb box;
+};
+
+constexpr int kThreads = 256;
+
+__device__ inline uint32_t spread3(uint32_t x) { // left_shift3, bvh.rs:903-912
+    if (x == (1u << 10)) x -= 1;
+    x = (x | (x << 16)) & 0x030000ffu;
+    x = (x | (x << 8)) & 0x0300f00fu;
+    x = (x | (x << 4)) & 0x030c30c3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+
+// bvh.rs:396-406 with the scale applied before the cast (the text casts first)
+__global__ void k_morton(const Aabb *bounds, uint32_t n, Aabb cb, uint32_t *codes, uint32_t *ids) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const Aabb b = bounds[i];
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float c = b.lo[k] * 0.5f + b.hi[k] * 0.5f; // BVHPrimitiveInfo::new, bvh.rs:694-703
+        float o = c - cb.lo[k];                          // Bounds3::offset, bounds3.rs:144-157
+        if (cb.hi[k] > cb.lo[k]) o /= cb.hi[k] - cb.lo[k];
+        q[k] = (uint32_t)(o * 1024.0f);
+    }
+    codes[i] = (spread3(q[2]) << 2) | (spread3(q[1]) << 1) | spread3(q[0]);
+    ids[i] = i;
+}
+
+__global__ void k_roots(const uint32_t *starts, uint32_t n_treelets, GNode *nodes) {
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n_treelets) return;
+    GNode g;
+    g.lo = starts[t];
+    g.hi = starts[t + 1];
+    g.bit = 29 - 12; // the top 12 bits are shared inside a treelet (bvh.rs:418)
+    g.child[0] = g.child[1] = -1;
+    g.treelet = t;
+    g.size = 1;
+    g.index = 0;
+    g.box = Aabb{{0, 0, 0}, {0, 0, 0}};
+    nodes[t] = g;
+}
+
+// One step of emit_lvbh (bvh.rs:452-538) for every node of a level.
+__global__ void k_split(GNode *nodes, uint32_t begin, uint32_t end, const uint32_t *codes, uint32_t max_prims,
+                        uint32_t *counter) {
+    const uint32_t id = begin + blockIdx.x * kThreads + threadIdx.x;
+    if (id >= end) return;
+    GNode g = nodes[id];
+    const uint32_t n = g.hi - g.lo;
+    const uint32_t *c = codes + g.lo;
+    int bit = g.bit;
+    for (;;) {
+        if (bit == -1 || n < max_prims) { // leaf, bvh.rs:459-480
+            nodes[id].child[0] = nodes[id].child[1] = -1;
+            return;
+        }
+        const uint32_t mask = 1u << bit;
+        if ((c[0] & mask) != (c[n - 1] & mask)) break;
+        bit--; // every primitive on the same side of this plane, bvh.rs:485-494
+    }
+    const uint32_t mask = 1u << bit;
+    uint32_t lo = 0, hi = n - 1; // bvh.rs:497-509
+    while (lo + 1 != hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if ((c[lo] & mask) == (c[mid] & mask)) lo = mid; else hi = mid;
+    }
+    const uint32_t first = atomicAdd(counter, 2u);
+    GNode a;
+    a.bit = bit - 1;
+    a.child[0] = a.child[1] = -1;
+    a.treelet = g.treelet;
+    a.size = 1;
+    a.index = 0;
+    a.box = Aabb{{0, 0, 0}, {0, 0, 0}};
+    a.lo = g.lo;
+    a.hi = g.lo + hi;
+    nodes[first] = a;
+    a.lo = g.lo + hi;
+    a.hi = g.hi;
+    nodes[first + 1] = a;
+    nodes[id].bit = bit;
+    nodes[id].child[0] = (int32_t)first;
+    nodes[id].child[1] = (int32_t)first + 1;
+}
+
+__device__ inline float pick_min(float a, float b) { return b < a ? b : a; }
+__device__ inline float pick_max(float a, float b) { return b > a ? b : a; }
+
+// boxes and subtree sizes, one level at a time from the deepest
+__global__ void k_up(GNode *nodes, uint32_t begin, uint32_t end, const Aabb *bounds, const uint32_t *ids,
+                     uint32_t *too_many) {
+    const uint32_t id = begin + blockIdx.x * kThreads + threadIdx.x;
+    if (id >= end) return;
+    GNode g = nodes[id];
+    const float m = 3.402823466e+38f;
+    Aabb box{{m, m, m}, {-m, -m, -m}};
+    uint32_t size = 1;
+    if (g.child[0] < 0) {
+        if (g.hi - g.lo > 65535u) atomicAdd(too_many, 1u);
+        for (uint32_t i = g.lo; i < g.hi; i++) {
+            const Aabb b = bounds[ids[i]];
+            for (int k = 0; k < 3; k++) {
+                box.lo[k] = pick_min(box.lo[k], b.lo[k]);
+                box.hi[k] = pick_max(box.hi[k], b.hi[k]);
+            }
+        }
+    } else {
+        const GNode &a = nodes[g.child[0]], &b = nodes[g.child[1]];
+        for (int k = 0; k < 3; k++) {
+            box.lo[k] = pick_min(a.box.lo[k], b.box.lo[k]);
+            box.hi[k] = pick_max(a.box.hi[k], b.box.hi[k]);
+        }
+        size = 1 + a.size + b.size;
+    }
+    nodes[id].box = box;
+    nodes[id].size = size;
+}
+
+// pre-order indices inside the treelet, one level at a time from the roots
+__global__ void k_down(GNode *nodes, uint32_t begin, uint32_t end) {
+    const uint32_t id = begin + blockIdx.x * kThreads + threadIdx.x;
+    if (id >= end) return;
+    const GNode g = nodes[id];
+    if (g.child[0] < 0) return;
+    nodes[g.child[0]].index = g.index + 1;
+    nodes[g.child[1]].index = g.index + 1 + nodes[g.child[0]].size;
+}
+
+__global__ void k_emit(const GNode *nodes, uint32_t n_nodes, const uint32_t *base, rt_linear_node *out) {
+    const uint32_t id = blockIdx.x * kThreads + threadIdx.x;
+    if (id >= n_nodes) return;
+    const GNode g = nodes[id];
+    const uint32_t b = base[g.treelet];
+    rt_linear_node ln;
+    for (int k = 0; k < 3; k++) {
+        ln.lo[k] = g.box.lo[k];
+        ln.hi[k] = g.box.hi[k];
+    }
+    ln._pad = 0;
+    if (g.child[0] < 0) {
+        ln.child_offset = g.lo;
+        ln.primitive_count = (uint16_t)(g.hi - g.lo);
+        ln.axis = 0;
+    } else {
+        ln.child_offset = b + nodes[g.child[1]].index;
+        ln.primitive_count = 0;
+        ln.axis = (uint8_t)(g.bit % 3);
+    }
+    out[b + g.index] = ln;
+}
+
+struct DeviceMem { // frees what it allocated when the build ends, on every path
+    std::vector<void *> blocks;
+    ~DeviceMem() {
+        for (void *p : blocks) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t get(T **p, size_t count) {
+        void *v = nullptr;
+        hipError_t e = hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) blocks.push_back(v);
+        *p = static_cast<T *>(v);
+        return e;
+    }
+};
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+} // namespace
+
+#define GPU_TRY(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return RT_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_in_node, int device,
+                            BuiltTree &out, std::string &err) {
+    out = BuiltTree();
+    const size_t n64 = bounds.size();
+    if (n64 == 0) return RT_OK;
+    if (n64 >= (1ull << 31)) {
+        err = "too many primitives for a device build";
+        return RT_ERR_LIMIT;
+    }
+    const uint32_t n = (uint32_t)n64;
+    uint32_t max_prims = max_prims_in_node ? max_prims_in_node : 4;
+    if (max_prims > 255) max_prims = 255; // bvh.rs:114
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        err = "no such HIP device for the build";
+        return RT_ERR_NO_DEVICE;
+    }
+    GPU_TRY(hipSetDevice(device));
+
+    // bounds of the centroids (bvh.rs:389-394): min / max, any order
+    Aabb cb = empty_box();
+    for (const Aabb &b : bounds)
+        for (int k = 0; k < 3; k++) {
+            const float c = b.lo[k] * 0.5f + b.hi[k] * 0.5f;
+            if (c < cb.lo[k]) cb.lo[k] = c;
+            if (c > cb.hi[k]) cb.hi[k] = c;
+        }
+
+    DeviceMem mem;
+    Aabb *d_bounds;
+    uint32_t *d_codes, *d_ids, *d_codes2, *d_ids2, *d_counter;
+    GPU_TRY(mem.get(&d_bounds, n));
+    GPU_TRY(mem.get(&d_codes, n));
+    GPU_TRY(mem.get(&d_ids, n));
+    GPU_TRY(mem.get(&d_codes2, n));
+    GPU_TRY(mem.get(&d_ids2, n));
+    GPU_TRY(mem.get(&d_counter, 2));
+    GPU_TRY(hipMemcpy(d_bounds, bounds.data(), n64 * sizeof(Aabb), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_bounds, n, cb, d_codes, d_ids);
+    GPU_TRY(hipGetLastError());
+
+    size_t temp_bytes = 0;
+    GPU_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_codes, d_codes2, d_ids, d_ids2, n, 0, 30));
+    char *d_temp;
+    GPU_TRY(mem.get(&d_temp, temp_bytes));
+    GPU_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_codes, d_codes2, d_ids, d_ids2, n, 0, 30));
+
+    // treelets: maximal runs with equal top 12 bits (bvh.rs:414-431)
+    std::vector<uint32_t> codes(n);
+    out.order.resize(n);
+    GPU_TRY(hipMemcpy(codes.data(), d_codes2, n64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    GPU_TRY(hipMemcpy(out.order.data(), d_ids2, n64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t mask = 0x3ffc0000u;
+    std::vector<uint32_t> starts;
+    for (uint32_t i = 0; i < n; i++)
+        if (i == 0 || (codes[i] & mask) != (codes[i - 1] & mask)) starts.push_back(i);
+    const uint32_t n_treelets = (uint32_t)starts.size();
+    starts.push_back(n);
+    std::vector<uint32_t>().swap(codes);
+
+    uint32_t *d_starts, *d_base;
+    GNode *d_nodes;
+    const size_t capacity = 2 * n64 + n_treelets;
+    GPU_TRY(mem.get(&d_starts, starts.size()));
+    GPU_TRY(mem.get(&d_base, n_treelets));
+    GPU_TRY(mem.get(&d_nodes, capacity));
+    GPU_TRY(hipMemcpy(d_starts, starts.data(), starts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_roots, dim3(blocks_for(n_treelets)), dim3(kThreads), 0, nullptr, d_starts, n_treelets, d_nodes);
+    const uint32_t init[2] = {n_treelets, 0}; // [0] next free node, [1] leaves above 65535 primitives
+    GPU_TRY(hipMemcpy(d_counter, init, sizeof init, hipMemcpyHostToDevice));
+
+    // breadth first: level k is nodes [level[k], level[k + 1])
+    std::vector<uint32_t> level{0, n_treelets};
+    for (;;) {
+        const uint32_t begin = level[level.size() - 2], end = level.back();
+        hipLaunchKernelGGL(k_split, dim3(blocks_for(end - begin)), dim3(kThreads), 0, nullptr, d_nodes, begin, end,
+                           d_codes2, max_prims, d_counter);
+        uint32_t next = 0;
+        GPU_TRY(hipMemcpy(&next, d_counter, sizeof next, hipMemcpyDeviceToHost));
+        if (next == end) break;
+        level.push_back(next);
+    }
+    const uint32_t n_nodes = level.back();
+    for (size_t k = level.size() - 1; k-- > 0;)
+        hipLaunchKernelGGL(k_up, dim3(blocks_for(level[k + 1] - level[k])), dim3(kThreads), 0, nullptr, d_nodes, level[k],
+                           level[k + 1], d_bounds, d_ids2, d_counter + 1);
+    for (size_t k = 0; k + 1 < level.size(); k++)
+        hipLaunchKernelGGL(k_down, dim3(blocks_for(level[k + 1] - level[k])), dim3(kThreads), 0, nullptr, d_nodes,
+                           level[k], level[k + 1]);
+    GPU_TRY(hipGetLastError());
+    uint32_t flags[2];
+    GPU_TRY(hipMemcpy(flags, d_counter, sizeof flags, hipMemcpyDeviceToHost));
+    if (flags[1]) {
+        err = "leaf with more than 65535 primitives";
+        return RT_ERR_LIMIT;
+    }
+
+    // the tree above the treelets, on the host
+    std::vector<GNode> roots(n_treelets);
+    GPU_TRY(hipMemcpy(roots.data(), d_nodes, (size_t)n_treelets * sizeof(GNode), hipMemcpyDeviceToHost));
+    std::vector<Aabb> boxes(n_treelets);
+    std::vector<uint32_t> sizes(n_treelets), base;
+    for (uint32_t t = 0; t < n_treelets; t++) {
+        boxes[t] = roots[t].box;
+        sizes[t] = roots[t].size;
+    }
+    std::vector<UpperNode> upper;
+    const uint32_t total = hlbvh_upper(boxes, sizes, upper, base);
+
+    rt_linear_node *d_out;
+    GPU_TRY(mem.get(&d_out, total));
+    GPU_TRY(hipMemcpy(d_base, base.data(), (size_t)n_treelets * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_emit, dim3(blocks_for(n_nodes)), dim3(kThreads), 0, nullptr, d_nodes, n_nodes, d_base, d_out);
+    GPU_TRY(hipGetLastError());
+    out.nodes.resize(total);
+    GPU_TRY(hipMemcpy(out.nodes.data(), d_out, (size_t)total * sizeof(rt_linear_node), hipMemcpyDeviceToHost));
+    for (const UpperNode &u : upper) out.nodes[u.index] = u.node;
+
+    out.max_depth = tree_depth(out.nodes);
+    if (out.max_depth > 64) { // nodes_to_visit = [0; 64], bvh.rs:753
+        err = "tree needs " + std::to_string(out.max_depth) + " stack entries, the traversal stack holds 64";
+        return RT_ERR_DEPTH;
+    }
+    return RT_OK;
+}
+
+} // namespace rt

@@ -117,6 +117,9 @@ class Builder {
         return root;
     }
 
+    // build_upper_sah over nodes the caller put into pool_ (one per treelet)
+    int32_t upper_of(std::vector<int32_t> &roots) { return upper(roots.data(), (uint32_t)roots.size()); }
+
     std::vector<BuildNode> pool_;
     std::vector<uint32_t> order_;
 
@@ -439,6 +442,56 @@ uint32_t flatten(const std::vector<BuildNode> &pool, int32_t id, std::vector<rt_
 }
 
 } // namespace
+
+uint32_t hlbvh_upper(const std::vector<Aabb> &boxes, const std::vector<uint32_t> &sizes,
+                     std::vector<UpperNode> &upper, std::vector<uint32_t> &base) {
+    const uint32_t n = (uint32_t)boxes.size();
+    upper.clear();
+    base.assign(n, 0);
+    if (n == 0) return 0;
+    Builder b(std::vector<Aabb>(), 1, RT_SPLIT_HLBVH);
+    std::vector<int32_t> roots(n);
+    for (uint32_t t = 0; t < n; t++) { // a treelet stands in the pool as a leaf whose `first` is its number
+        b.pool_.emplace_back();
+        b.pool_.back().box = boxes[t];
+        b.pool_.back().first = t;
+        roots[t] = (int32_t)t;
+    }
+    const int32_t root = b.upper_of(roots);
+    // pre-order numbering (flatten_tree, bvh.rs:661-691) with a treelet taking sizes[t] slots
+    uint32_t next = 0;
+    struct Walk {
+        const std::vector<BuildNode> &pool;
+        const std::vector<uint32_t> &sizes;
+        std::vector<UpperNode> &upper;
+        std::vector<uint32_t> &base;
+        uint32_t &next;
+        uint32_t go(int32_t id) {
+            const BuildNode &nd = pool[id];
+            const uint32_t idx = next;
+            if (nd.child[0] < 0) {
+                base[nd.first] = idx;
+                next += sizes[nd.first];
+                return idx;
+            }
+            next++;
+            const size_t slot = upper.size();
+            upper.emplace_back();
+            rt_linear_node ln;
+            memset(&ln, 0, sizeof ln);
+            memcpy(ln.lo, nd.box.lo, sizeof ln.lo);
+            memcpy(ln.hi, nd.box.hi, sizeof ln.hi);
+            ln.axis = (uint8_t)nd.axis;
+            go(nd.child[0]);
+            ln.child_offset = go(nd.child[1]);
+            upper[slot].index = idx;
+            upper[slot].node = ln;
+            return idx;
+        }
+    } walk{b.pool_, sizes, upper, base, next};
+    walk.go(root);
+    return next;
+}
 
 uint32_t tree_depth(const std::vector<rt_linear_node> &nodes) {
     if (nodes.empty()) return 0;

@@ -34,4 +34,21 @@ int build_tree(const std::vector<Aabb> &bounds, uint32_t max_prims_in_node, uint
 
 uint32_t tree_depth(const std::vector<rt_linear_node> &nodes);
 
+// The part of an HLBVH above its treelets (build_upper_sah, bvh.rs:541-658) for treelets
+// built elsewhere.  In: box and node count of every treelet, in Morton order.  Out: the
+// interior nodes above the treelets with their indices in the final pre-order array, and
+// base[t] = index of treelet t's root there.  Returns the size of the final array.
+struct UpperNode {
+    uint32_t index;
+    rt_linear_node node;
+};
+uint32_t hlbvh_upper(const std::vector<Aabb> &boxes, const std::vector<uint32_t> &sizes,
+                     std::vector<UpperNode> &upper, std::vector<uint32_t> &base);
+
+// HLBVH (hlbvh_build, bvh.rs:385-449) with Morton codes, the radix sort and the treelets
+// (emit_lvbh, bvh.rs:452-538) computed on HIP device `device`; same tree as build_tree with
+// RT_SPLIT_HLBVH, node for node.  Defined in rt_build_gpu.hip.
+int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_in_node, int device,
+                            BuiltTree &out, std::string &err);
+
 } // namespace rt

@@ -78,12 +78,14 @@ class Scene:
     ``Primitive::{world_bound, intersect, does_intersect}``
     (shapes/src/primitive.rs:8-27, shapes/src/bvh.rs:727-863)."""
 
-    def __init__(self, frozen, max_prims_in_node=4, split_method=abi.RT_SPLIT_SAH, device=0):
+    def __init__(self, frozen, max_prims_in_node=4, split_method=abi.RT_SPLIT_SAH, device=0,
+                 build_on_device=False):
         self._lib = load()
         self._frozen = frozen  # keeps the description's arrays alive during create
         self.device = device
         h = C.c_void_p()
-        opts = abi.rt_build_opts(max_prims_in_node, split_method)
+        opts = abi.rt_build_opts(max_prims_in_node, split_method,
+                                 abi.RT_BUILD_ON_DEVICE if build_on_device else 0, device)
         check(self._lib.rt_scene_create(C.byref(frozen.desc), C.byref(opts), C.byref(h)))
         self._h = h
 
