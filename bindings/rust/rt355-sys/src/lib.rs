@@ -84,7 +84,7 @@ pub struct rt_camera { pub raster_to_camera: [f32; 16], pub camera_to_world: [f3
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_filter { pub kind: u32, pub radius: [f32; 2], pub a: f32, pub b: f32, pub _pad: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
-pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub max_depth: u32, pub seed: u64, pub shard_index: u32, pub shard_count: u32, pub max_paths: u32, pub flags: u32, pub filter: rt_filter }
+pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub max_depth: u32, pub seed: u64, pub shard_index: u32, pub shard_count: u32, pub max_paths: u32, pub flags: u32, pub filter: rt_filter, pub sampler: u32, pub _pad: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct rt_stats {
     pub paths: u64, pub segments: u64, pub nodes_visited: u64, pub prims_tested: [u64; 8],

@@ -265,6 +265,14 @@ typedef struct rt_filter {
 #define RT_FILTER_MAX_RADIUS 8.0f
 #define RT_FILTER_TABLE_WIDTH 16 /* FILTER_TABLE_WIDTH, colour/src/film.rs:43      */
 
+/* Where a path's camera sample (film x, film y, time, lens u, lens v) comes from.
+ * Scattering always draws from the path's PCG32 stream (geometry/src/rng.rs). */
+typedef enum rt_sampler_kind {
+    RT_SAMPLER_RANDOM = 0, /* five PCG32 draws                                     */
+    RT_SAMPLER_HALTON = 1  /* Halton::sample_dimension, colour/src/samplers/halton.rs:
+                              dimensions 0-4 of the Halton sequence, pixel-aligned  */
+} rt_sampler_kind;
+
 typedef struct rt_render_opts {
     uint32_t width, height;
     uint32_t spp;
@@ -275,6 +283,8 @@ typedef struct rt_render_opts {
     uint32_t max_paths;   /* paths in flight per batch; 0 = library default       */
     uint32_t flags;
     rt_filter filter;     /* Film's filter (film.rs:20); kind 0 = none             */
+    uint32_t sampler;     /* rt_sampler_kind                                      */
+    uint32_t _pad;
 } rt_render_opts;
 
 typedef struct rt_stats {

@@ -43,6 +43,7 @@ int orc_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t
                       size_t n, rt_ray *rays);
 /* Film::new's filter table (colour/src/film.rs:99-113) and write_image's
  * normalisation (film.rs:236-247). */
+void orc_camera_sample_test(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, float u[5]);
 int orc_filter_table(const rt_filter *filter, float out[256]);
 void orc_film_resolve(float *rgba, uint32_t width, uint32_t height);
 int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,

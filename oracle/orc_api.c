@@ -443,9 +443,10 @@ static int render_filtered(const orc_scene *s, const rt_camera *cam, const rt_re
                         if (!pixel_owned(opts, (uint32_t)qx, (uint32_t)qy)) continue;
                         uint64_t path = ((uint64_t)qy * W + (uint64_t)qx) * spp + k;
                         orc_rng rng;
+                        float u[5];
                         orc_rng_seq(&rng, (opts->seed << 32) + path);
-                        float u1 = orc_rng_f(&rng), u2 = orc_rng_f(&rng);
-                        float dx = ((float)qx + u1) - 0.5f, dy = ((float)qy + u2) - 0.5f;
+                        orc_camera_sample(opts, (uint32_t)qx, (uint32_t)qy, k, &rng, u);
+                        float dx = ((float)qx + u[0]) - 0.5f, dy = ((float)qy + u[1]) - 0.5f;
                         float fxp = (float)x, fyp = (float)y;
                         if (fxp < ceilf(dx - rx) || fxp > floorf(dx + rx)) continue;
                         if (fyp < ceilf(dy - ry) || fyp > floorf(dy + ry)) continue;

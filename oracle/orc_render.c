@@ -89,16 +89,129 @@ void orc_camera_ray(const rt_camera *cam, float fx, float fy, float lu, float lv
     out->time = time;
 }
 
+/* ---- Halton camera samples: colour/src/samplers/halton.rs + low_discrepancy.rs --------
+ * Deviations from the literal text, following pbrt-v3 which it transcribes: dimension 1
+ * divides the index by base_scales[1] (halton.rs:98 shifts by it).  Permutations are
+ * data/src/lib.rs:16-41: the digits of each prime shuffled by one Rng::default() stream,
+ * primes in order; only those of 5, 7 and 11 (dimensions 2-4) are used here. */
+static uint8_t g_perm[28];
+static int g_perm_ready;
+static const uint32_t kPrime[5] = {2, 3, 5, 7, 11}, kPrimeSum[5] = {0, 2, 5, 10, 17};
+
+static void halton_perms(void) {
+    orc_rng rng = {0x853c49e6748fea9bULL, 0xda3e39cb94b95bdbULL}; /* Rng::default, rng.rs:15-22 */
+    uint8_t perm[28];
+    for (int i = 0; i < 5; i++) {
+        uint8_t *p = perm + kPrimeSum[i];
+        uint32_t n = kPrime[i];
+        for (uint32_t j = 0; j < n; j++) p[j] = (uint8_t)j;
+        for (uint32_t j = 0; j < n; j++) { /* shuffle_dims(.., 1), rng.rs:77-84 */
+            uint32_t other = j + orc_rng_limit(&rng, n - j);
+            uint8_t t = p[j]; p[j] = p[other]; p[other] = t;
+        }
+    }
+    memcpy(g_perm, perm, sizeof perm);
+    __atomic_store_n(&g_perm_ready, 1, __ATOMIC_RELEASE);
+}
+
+static float radical_inverse(uint32_t base, uint64_t num) { /* low_discrepancy.rs:7-21 */
+    float inv = 1.0f / (float)base, inv_base_n = 1.0f;
+    uint64_t digits = 0;
+    while (num > 0) {
+        uint64_t next = num / base, digit = num - next * base;
+        digits = digits * base + digit;
+        inv_base_n *= inv;
+        num = next;
+    }
+    float v = (float)(double)digits * inv_base_n;
+    return v < 0.99999994f ? v : 0.99999994f;
+}
+
+static float scrambled_radical_inverse(uint32_t base, uint64_t num, const uint8_t *perm) { /* :43-62 */
+    float inv = 1.0f / (float)base, inv_base_n = 1.0f;
+    uint64_t digits = 0;
+    while (num > 0) {
+        uint64_t next = num / base, digit = num - next * base;
+        digits = digits * base + perm[digit];
+        inv_base_n *= inv;
+        num = next;
+    }
+    float v = inv_base_n * ((float)(double)digits + inv * (float)perm[0] / (1.0f - inv));
+    return v < 0.99999994f ? v : 0.99999994f;
+}
+
+static uint64_t inverse_radical_inverse(uint32_t base, uint64_t inverse, uint32_t n_digits) { /* :31-40 */
+    uint64_t index = 0;
+    for (uint32_t i = 0; i < n_digits; i++) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+
+static int64_t ext_gcd_x(int64_t a, int64_t b, int64_t *y) { /* halton.rs:119-126 */
+    if (b == 0) { *y = 0; return 1; }
+    int64_t yp, xp = ext_gcd_x(b, a % b, &yp);
+    *y = xp - (a / b) * yp;
+    return yp;
+}
+static uint64_t mult_inverse(int64_t a, int64_t n) { /* halton.rs:113-116 */
+    int64_t y, x = ext_gcd_x(a, n, &y);
+    int64_t r = x % n;
+    return (uint64_t)(r < 0 ? r + n : r);
+}
+
+static void halton_sample(const rt_render_opts *o, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
+    if (!__atomic_load_n(&g_perm_ready, __ATOMIC_ACQUIRE)) halton_perms();
+    uint32_t res[2] = {o->width, o->height}, scale[2], expo[2];
+    for (int i = 0; i < 2; i++) { /* Halton::new, halton.rs:33-45: 2^j, 3^k >= min(res, 128) */
+        uint32_t base = (uint32_t)i + 2, sc = 1, e = 0, lim = res[i] < 128 ? res[i] : 128;
+        while (sc < lim) { sc *= base; e++; }
+        scale[i] = sc; expo[i] = e;
+    }
+    uint64_t stride = (uint64_t)scale[0] * scale[1], offset = 0;
+    if (stride > 1) { /* get_index_for_sample, halton.rs:62-86 */
+        uint32_t pm[2] = {px % 128, py % 128};
+        uint64_t mi[2] = {mult_inverse(scale[1], scale[0]), mult_inverse(scale[0], scale[1])};
+        for (int i = 0; i < 2; i++) {
+            uint64_t d = inverse_radical_inverse((uint32_t)i + 2, pm[i], expo[i]);
+            offset += d * (stride / scale[i]) * mi[i];
+        }
+        offset %= stride;
+    }
+    uint64_t index = offset + (uint64_t)s * stride;
+    u[0] = radical_inverse(2, index >> expo[0]); /* sample_dimension, halton.rs:90-106 */
+    u[1] = radical_inverse(3, index / scale[1]);
+    u[2] = scrambled_radical_inverse(5, index, g_perm + kPrimeSum[2]);
+    u[3] = scrambled_radical_inverse(7, index, g_perm + kPrimeSum[3]);
+    u[4] = scrambled_radical_inverse(11, index, g_perm + kPrimeSum[4]);
+}
+
+void orc_camera_sample(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, orc_rng *rng, float u[5]) {
+    if (opts->sampler == RT_SAMPLER_HALTON) {
+        halton_sample(opts, px, py, s, u);
+    } else {
+        for (int k = 0; k < 5; k++) u[k] = orc_rng_f(rng);
+    }
+}
+
+/* known-answer hook for the tests: the camera sample without a generator (Halton only) */
+void orc_camera_sample_test(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
+    orc_rng rng = {0, 1};
+    orc_camera_sample(opts, px, py, s, &rng, u);
+}
+
 /* path p = pixel * spp + sample; its PCG32 sequence index is seed * 2^32 + p.
- * Sample order: film x, film y, time, lens u, lens v. */
+ * Camera sample order: film x, film y, time, lens u, lens v. */
 void orc_path_setup(const rt_camera *cam, const rt_render_opts *opts, uint64_t path, orc_rng *rng,
                     rt_ray *ray) {
     uint64_t pixel = path / opts->spp;
     uint32_t px = (uint32_t)(pixel % opts->width), py = (uint32_t)(pixel / opts->width);
     orc_rng_seq(rng, (opts->seed << 32) + path);
-    float u1 = orc_rng_f(rng), u2 = orc_rng_f(rng), ut = orc_rng_f(rng);
-    float l1 = orc_rng_f(rng), l2 = orc_rng_f(rng);
-    orc_camera_ray(cam, (float)px + u1, (float)py + u2, l1, l2, ut, ray);
+    float u[5];
+    orc_camera_sample(opts, px, py, (uint32_t)(path % opts->spp), rng, u);
+    orc_camera_ray(cam, (float)px + u[0], (float)py + u[1], u[3], u[4], u[2], ray);
 }
 
 /* ---- textures ---------------------------------------------------------------- */

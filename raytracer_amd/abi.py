@@ -100,7 +100,10 @@ class rt_render_opts(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("max_depth", C.c_uint32), ("seed", C.c_uint64), ("shard_index", C.c_uint32),
                 ("shard_count", C.c_uint32), ("max_paths", C.c_uint32), ("flags", C.c_uint32),
-                ("filter", rt_filter)]
+                ("filter", rt_filter), ("sampler", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+RT_SAMPLER_RANDOM, RT_SAMPLER_HALTON = 0, 1
 
 
 class rt_stats(C.Structure):

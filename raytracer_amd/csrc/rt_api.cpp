@@ -755,13 +755,76 @@ int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t 
     HIP_TRY(hipSetDevice(device));
     rt_ray *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, n * sizeof(rt_ray)));
-    hipError_t e = rt::launch_generate_rays(*cam, opts->width, opts->spp, opts->seed, first_path, (uint32_t)n,
-                                            d, nullptr);
+    rt::FrameDev F{opts->width, opts->height, opts->spp, (opts->width + 31) / 32, 0, 1, opts->seed, opts->sampler, {}};
+    if (opts->sampler == RT_SAMPLER_HALTON) rt::halton_setup(opts->width, opts->height, F.halton);
+    hipError_t e = rt::launch_generate_rays(F, *cam, first_path, (uint32_t)n, d, nullptr);
     if (e == hipSuccess) e = hipMemcpy(rays, d, n * sizeof(rt_ray), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "ray generation failed: %s", hipGetErrorString(e));
     return RT_OK;
 }
+
+extern "C++" {
+namespace rt {
+
+// Halton::new, colour/src/samplers/halton.rs:25-52, and the permutation table of
+// data/src/lib.rs:16-41 (digits of each prime shuffled by one Rng::default() stream).
+void halton_setup(uint32_t width, uint32_t height, HaltonDev &h) {
+    const uint32_t res[2] = {width, height};
+    for (int i = 0; i < 2; i++) {
+        const uint32_t base = (uint32_t)i + 2, limit = std::min(res[i], 128u);
+        uint32_t scale = 1, exponent = 0;
+        while (scale < limit) {
+            scale *= base;
+            exponent++;
+        }
+        h.scale[i] = scale;
+        h.exponent[i] = exponent;
+    }
+    h.stride = h.scale[0] * h.scale[1];
+    struct Gcd { // extended_gcd / multiplicative_inverse, halton.rs:113-126
+        static void run(int64_t a, int64_t b, int64_t &x, int64_t &y) {
+            if (b == 0) { x = 1; y = 0; return; }
+            int64_t xp, yp;
+            run(b, a % b, xp, yp);
+            x = yp;
+            y = xp - (a / b) * yp;
+        }
+        static uint32_t inverse(int64_t a, int64_t n) {
+            int64_t x, y;
+            run(a, n, x, y);
+            const int64_t r = x % n;
+            return (uint32_t)(r < 0 ? r + n : r);
+        }
+    };
+    h.mult_inv[0] = Gcd::inverse(h.scale[1], h.scale[0]);
+    h.mult_inv[1] = Gcd::inverse(h.scale[0], h.scale[1]);
+    uint64_t state = 0x853c49e6748fea9bULL; // Rng::default, geometry/src/rng.rs:15-22
+    const uint64_t inc = 0xda3e39cb94b95bdbULL;
+    auto next = [&]() { // uniform_u32, rng.rs:41-47
+        const uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        const uint32_t shifted = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+        return (shifted >> rot) | (shifted << ((~rot + 1u) & 31u));
+    };
+    auto below = [&](uint32_t limit) { // uniform_u32_limit, rng.rs:50-58
+        const uint32_t threshold = (~limit + 1u) % limit;
+        for (;;) {
+            const uint32_t r = next();
+            if (r >= threshold) return r % limit;
+        }
+    };
+    const uint32_t primes[5] = {2, 3, 5, 7, 11};
+    uint8_t *p = h.perm;
+    for (uint32_t n : primes) {
+        for (uint32_t j = 0; j < n; j++) p[j] = (uint8_t)j;
+        for (uint32_t j = 0; j < n; j++) std::swap(p[j], p[j + below(n - j)]); // shuffle_dims(.., 1), rng.rs:77-84
+        p += n;
+    }
+}
+
+} // namespace rt
+} // extern "C++"
 
 namespace {
 
@@ -851,7 +914,10 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     }
     std::lock_guard<std::mutex> g(db->render_lock);
 
-    rt::FrameDev F{o->width, o->height, o->spp, (o->width + 31) / 32, o->shard_index, shard_count, o->seed};
+    if (o->sampler > RT_SAMPLER_HALTON) return fail(RT_ERR_INVALID, "unknown sampler");
+    rt::FrameDev F{o->width, o->height, o->spp, (o->width + 31) / 32, o->shard_index, shard_count, o->seed,
+                   o->sampler, {}};
+    if (o->sampler == RT_SAMPLER_HALTON) rt::halton_setup(o->width, o->height, F.halton);
     const uint32_t tiles = F.tiles_x * ((o->height + 31) / 32);
     const uint32_t my_tiles = tiles > o->shard_index ? (tiles - o->shard_index + shard_count - 1) / shard_count : 0;
     const uint32_t n_ranks = my_tiles * 1024;

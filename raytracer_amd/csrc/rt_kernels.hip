@@ -597,23 +597,88 @@ RT_DEV Ray camera_ray(const rt_camera &cam, float fx, float fy, float lu, float 
     return r;
 }
 
-// Path of pixel (px, py), global id `path` = pixel * spp + sample; PCG32 sequence =
-// seed * 2^32 + path; draws: film x, film y, time, lens u, lens v.
-RT_DEV Ray path_setup(const rt_camera &cam, uint32_t px, uint32_t py, uint64_t seed, uint64_t path, Rng &rng) {
-    rng_seq(rng, (seed << 32) + path);
-    float u1 = rng_f(rng), u2 = rng_f(rng), ut = rng_f(rng);
-    float l1 = rng_f(rng), l2 = rng_f(rng);
-    return camera_ray(cam, (float)px + u1, (float)py + u2, l1, l2, ut);
+// ---- Halton camera samples: colour/src/samplers/halton.rs + low_discrepancy.rs ------------
+template <uint32_t BASE>
+RT_DEV float radical_inverse(uint64_t num) { // low_discrepancy.rs:7-21
+    const float inv = 1.0f / (float)BASE;
+    float inv_base_n = 1.0f;
+    uint64_t digits = 0;
+    while (num > 0) {
+        const uint64_t next = num / BASE, digit = num - next * BASE;
+        digits = digits * BASE + digit;
+        inv_base_n *= inv;
+        num = next;
+    }
+    return sel_min((float)(double)digits * inv_base_n, 0.99999994f);
+}
+template <uint32_t BASE>
+RT_DEV float scrambled_radical_inverse(uint64_t num, const uint8_t *perm) { // low_discrepancy.rs:43-62
+    const float inv = 1.0f / (float)BASE;
+    float inv_base_n = 1.0f;
+    uint64_t digits = 0;
+    while (num > 0) {
+        const uint64_t next = num / BASE, digit = num - next * BASE;
+        digits = digits * BASE + perm[digit];
+        inv_base_n *= inv;
+        num = next;
+    }
+    return sel_min(inv_base_n * ((float)(double)digits + inv * (float)perm[0] / (1.0f - inv)), 0.99999994f);
+}
+template <uint32_t BASE>
+RT_DEV uint64_t inverse_radical_inverse(uint64_t inverse, uint32_t n_digits) { // low_discrepancy.rs:31-40
+    uint64_t index = 0;
+    for (uint32_t i = 0; i < n_digits; i++) {
+        const uint64_t digit = inverse % BASE;
+        inverse /= BASE;
+        index = index * BASE + digit;
+    }
+    return index;
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate_rays(rt_camera cam, uint32_t width, uint32_t spp,
-                                                          uint64_t seed, uint64_t first, uint32_t n,
+// get_index_for_sample + sample_dimension (halton.rs:62-106) for dimensions 0-4; dimension 1
+// divides the index by base_scales[1] as pbrt does (halton.rs:98 shifts by it)
+RT_DEV void halton_sample(const HaltonDev &h, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
+    uint64_t offset = 0;
+    if (h.stride > 1) {
+        const uint64_t d0 = inverse_radical_inverse<2>(px % 128u, h.exponent[0]);
+        const uint64_t d1 = inverse_radical_inverse<3>(py % 128u, h.exponent[1]);
+        offset = d0 * (h.stride / h.scale[0]) * h.mult_inv[0] + d1 * (h.stride / h.scale[1]) * h.mult_inv[1];
+        offset %= h.stride;
+    }
+    const uint64_t index = offset + (uint64_t)s * h.stride;
+    u[0] = radical_inverse<2>(index >> h.exponent[0]);
+    u[1] = radical_inverse<3>(index / h.scale[1]);
+    u[2] = scrambled_radical_inverse<5>(index, h.perm + 5);
+    u[3] = scrambled_radical_inverse<7>(index, h.perm + 10);
+    u[4] = scrambled_radical_inverse<11>(index, h.perm + 17);
+}
+
+// Camera sample of path (pixel, s): film offsets u[0], u[1], time u[2], lens u[3], u[4].
+RT_DEV void camera_sample(const FrameDev &F, uint32_t px, uint32_t py, uint32_t s, Rng &rng, float u[5]) {
+    if (F.sampler == RT_SAMPLER_HALTON) {
+        halton_sample(F.halton, px, py, s, u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) u[k] = rng_f(rng);
+    }
+}
+
+// Path of pixel (px, py), global id `path` = pixel * spp + sample; PCG32 sequence =
+// seed * 2^32 + path; camera sample order: film x, film y, time, lens u, lens v.
+RT_DEV Ray path_setup(const FrameDev &F, const rt_camera &cam, uint32_t px, uint32_t py, uint64_t path, Rng &rng) {
+    rng_seq(rng, (F.seed << 32) + path);
+    float u[5];
+    camera_sample(F, px, py, (uint32_t)(path % F.spp), rng, u);
+    return camera_ray(cam, (float)px + u[0], (float)py + u[1], u[3], u[4], u[2]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate_rays(FrameDev F, rt_camera cam, uint64_t first, uint32_t n,
                                                           rt_ray *rays) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Rng rng;
-    uint64_t path = first + i, pixel = path / spp;
-    Ray r = path_setup(cam, (uint32_t)(pixel % width), (uint32_t)(pixel / width), seed, path, rng);
+    uint64_t path = first + i, pixel = path / F.spp;
+    Ray r = path_setup(F, cam, (uint32_t)(pixel % F.width), (uint32_t)(pixel / F.width), path, rng);
     float4 *o = reinterpret_cast<float4 *>(rays + i);
     o[0] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
     o[1] = make_float4(r.d.y, r.d.z, r.t_max, r.time);
@@ -659,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, 
         uint32_t rank = local / s_count, s = s0 + local % s_count, px, py;
         if (rank_to_pixel(F, rank, px, py)) {
             gpath = (py * F.width + px) * F.spp + s;
-            ray = path_setup(cam, px, py, F.seed, gpath, rng);
+            ray = path_setup(F, cam, px, py, gpath, rng);
             alive = true;
         }
     }
@@ -1122,9 +1187,10 @@ __global__ __launch_bounds__(kBlock) void k_film(FrameDev F, FilterDev T, const 
                 const uint32_t rank = (tile / F.shard_count) * 1024u + (((uint32_t)qy & 31u) << 5) + ((uint32_t)qx & 31u);
                 const uint64_t path = ((uint64_t)qy * F.width + (uint64_t)qx) * F.spp + (s0 + k);
                 Rng rng;
+                float u[5];
                 rng_seq(rng, (F.seed << 32) + path);
-                const float u1 = rng_f(rng), u2 = rng_f(rng);
-                const float dx = ((float)qx + u1) - 0.5f, dy = ((float)qy + u2) - 0.5f;
+                camera_sample(F, (uint32_t)qx, (uint32_t)qy, s0 + k, rng, u);
+                const float dx = ((float)qx + u[0]) - 0.5f, dy = ((float)qy + u[1]) - 0.5f;
                 if (fxp < ceilf(dx - T.rx) || fxp > floorf(dx + T.rx)) continue;
                 if (fyp < ceilf(dy - T.ry) || fyp > floorf(dy + T.ry)) continue;
                 int ix = (int)floorf(fabsf((fxp - dx) * inv_rx * 16.0f));
@@ -1206,10 +1272,10 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
     return hipGetLastError();
 }
 
-hipError_t launch_generate_rays(const rt_camera &cam, uint32_t width, uint32_t spp, uint64_t seed,
-                                uint64_t first, uint32_t n, rt_ray *rays, hipStream_t stream) {
-    hipLaunchKernelGGL(k_generate_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cam, width,
-                       spp, seed, first, n, rays);
+hipError_t launch_generate_rays(const FrameDev &F, const rt_camera &cam, uint64_t first, uint32_t n,
+                                rt_ray *rays, hipStream_t stream) {
+    hipLaunchKernelGGL(k_generate_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, cam, first, n,
+                       rays);
     return hipGetLastError();
 }
 

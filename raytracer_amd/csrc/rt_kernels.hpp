@@ -27,12 +27,27 @@ struct Queue {
     uint32_t cap;
 };
 
+// Halton::new (colour/src/samplers/halton.rs:25-52) for one frame size, plus the digit
+// permutations of the primes 5, 7 and 11 (data/src/lib.rs:16-41) that dimensions 2-4 use.
+struct HaltonDev {
+    uint32_t scale[2];    // 2^j, 3^k >= min(resolution, 128)
+    uint32_t exponent[2]; // j, k
+    uint32_t mult_inv[2];
+    uint32_t stride;      // scale[0] * scale[1]
+    uint8_t perm[28];     // by prime: 2, 3, 5, 7, 11 at offsets 0, 2, 5, 10, 17
+};
+
 struct FrameDev {
     uint32_t width, height, spp;
     uint32_t tiles_x;
     uint32_t shard_index, shard_count;
     uint64_t seed;
+    uint32_t sampler; // rt_sampler_kind
+    HaltonDev halton;
 };
+
+// Fills `h` for a width x height frame (host).
+void halton_setup(uint32_t width, uint32_t height, HaltonDev &h);
 
 // How the trace kernels are launched for one scene on one device.
 struct LaunchShape {
@@ -50,8 +65,8 @@ hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ra
                             rt_hit *hits, unsigned long long *counters, hipStream_t stream);
 hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
                            hipStream_t stream);
-hipError_t launch_generate_rays(const rt_camera &cam, uint32_t width, uint32_t spp, uint64_t seed,
-                                uint64_t first, uint32_t n, rt_ray *rays, hipStream_t stream);
+hipError_t launch_generate_rays(const FrameDev &F, const rt_camera &cam, uint64_t first, uint32_t n,
+                                rt_ray *rays, hipStream_t stream);
 hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
                            uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream);
 // Per-wave memory of the bounce kernel: two lists of parked hit records (kParkSlots x 24
