@@ -179,7 +179,7 @@ def test_render_mixed_and_sharded():
 
 
 def test_full_size_properties(scene_cache):
-    """BASELINE-size frame (week scene, 1920x1080): checked through properties that do
+    """Full-size frame (week scene, 1920x1080): checked through properties that do
     not need the oracle at full size -- a sample of its paths against the oracle,
     determinism, and independence of the batch size."""
     sd, cam, fr = scene_cache("week")

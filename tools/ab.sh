@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of prebuilt library variants (variants/librt355_<tag>.so): bench + traversal micro-benchmark each.
+# A/B of prebuilt library variants (variants/librt355_<tag>.so, built by hand with extra -D flags): bench + traversal micro-benchmark each.
 # usage: tools/ab.sh tag1 tag2 ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for T in "$@"; do

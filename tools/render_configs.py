@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Renders the BASELINE configurations at full size on one GPU and prints one JSON
+"""Renders the five benchmark configurations at full size on one GPU and prints one JSON
 line each: Mrays/s, ms/frame, traversal counters, algorithmic bytes, and a
 bit-exactness spot check of sampled pixels against the CPU oracle.
 usage: render_configs.py [C1|C2|C3|C4|C5 ...] [--spp-scale F] [--check N]"""
