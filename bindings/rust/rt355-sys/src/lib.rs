@@ -84,7 +84,7 @@ pub struct rt_camera { pub raster_to_camera: [f32; 16], pub camera_to_world: [f3
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_filter { pub kind: u32, pub radius: [f32; 2], pub a: f32, pub b: f32, pub _pad: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
-pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub max_depth: u32, pub seed: u64, pub shard_index: u32, pub shard_count: u32, pub max_paths: u32, pub flags: u32, pub filter: rt_filter, pub sampler: u32, pub _pad: u32 }
+pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub max_depth: u32, pub seed: u64, pub shard_index: u32, pub shard_count: u32, pub max_paths: u32, pub flags: u32, pub filter: rt_filter, pub sampler: u32, pub sampler_arg: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct rt_stats {
     pub paths: u64, pub segments: u64, pub nodes_visited: u64, pub prims_tested: [u64; 8],
@@ -111,6 +111,7 @@ extern "C" {
     pub fn rt_render(scene: *mut rt_scene, cam: *const rt_camera, opts: *const rt_render_opts, rgba_out: *mut f32, stats: *mut rt_stats, device: c_int) -> c_int;
     pub fn rt_render_dev(scene: *mut rt_scene, cam: *const rt_camera, opts: *const rt_render_opts, d_rgba_out: *mut f32, stats: *mut rt_stats, device: c_int, stream: *mut c_void) -> c_int;
     pub fn rt_filter_table(filter: *const rt_filter, out: *mut f32) -> c_int;
+    pub fn rt_sobol_tables(width: u32, height: u32, m32: *mut u32, vdc: *mut u64, inv: *mut u64) -> c_int;
     pub fn rt_film_resolve_dev(d_rgba: *mut f32, width: u32, height: u32, device: c_int, stream: *mut c_void) -> c_int;
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_abi_sizes(out: *mut u32, cap: usize) -> c_int;

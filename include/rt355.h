@@ -268,10 +268,21 @@ typedef struct rt_filter {
 /* Where a path's camera sample (film x, film y, time, lens u, lens v) comes from.
  * Scattering always draws from the path's PCG32 stream (geometry/src/rng.rs). */
 typedef enum rt_sampler_kind {
-    RT_SAMPLER_RANDOM = 0, /* five PCG32 draws                                     */
-    RT_SAMPLER_HALTON = 1  /* Halton::sample_dimension, colour/src/samplers/halton.rs:
-                              dimensions 0-4 of the Halton sequence, pixel-aligned  */
+    RT_SAMPLER_RANDOM = 0,    /* five PCG32 draws                                  */
+    RT_SAMPLER_HALTON = 1,    /* Halton::sample_dimension, colour/src/samplers/halton.rs:
+                                 dimensions 0-4 of the Halton sequence, pixel-aligned */
+    RT_SAMPLER_SOBOL = 2,     /* Sobol::get_index_for_sample / sample_dimension,
+                                 colour/src/samplers/sobol.rs:31-95: dimensions 0-4 of
+                                 the Sobol' sequence, pixel-aligned                   */
+    RT_SAMPLER_ZERO_TWO = 3,  /* ZeroTwo::start_pixel, colour/src/samplers/zero_two.rs:
+                                 scrambled, shuffled (0,2)-sequence points per pixel;
+                                 spp must be a power of two (ZeroTwo::new rounds up)  */
+    RT_SAMPLER_STRATIFIED = 4 /* Stratified::start_pixel, colour/src/samplers/
+                                 stratified.rs: sampler_arg bits 0-15 = x strata,
+                                 y strata = spp / x strata (must divide)              */
 } rt_sampler_kind;
+
+#define RT_STRATIFIED_NO_JITTER 0x80000000u /* samples at the stratum centres (jitter_samples = false) */
 
 typedef struct rt_render_opts {
     uint32_t width, height;
@@ -284,7 +295,7 @@ typedef struct rt_render_opts {
     uint32_t flags;
     rt_filter filter;     /* Film's filter (film.rs:20); kind 0 = none             */
     uint32_t sampler;     /* rt_sampler_kind                                      */
-    uint32_t _pad;
+    uint32_t sampler_arg; /* RT_SAMPLER_STRATIFIED: x strata | RT_STRATIFIED_NO_JITTER */
 } rt_render_opts;
 
 typedef struct rt_stats {
@@ -369,6 +380,12 @@ int rt_render_dev(rt_scene *scene, const rt_camera *cam, const rt_render_opts *o
 /* The 16 x 16 table of filter values Film::new precomputes (film.rs:99-113):
  * out[y * 16 + x] = eval((x + 0.5) * radius.x / 16, (y + 0.5) * radius.y / 16). */
 int rt_filter_table(const rt_filter *filter, float out[256]);
+
+/* The Sobol' tables RT_SAMPLER_SOBOL uses for a width x height frame, as data/src/sobol.rs
+ * holds them: m32 = MATRICES_32[0 .. 5*52) (:68), vdc = MATRICES[m - 1] (:59978) and
+ * inv = MATRICES_INV[m - 1] (:60151) for m = log2 of the frame's power-of-two resolution
+ * (zeros when m = 0).  Computed from the Joe-Kuo direction numbers, not stored. */
+int rt_sobol_tables(uint32_t width, uint32_t height, uint32_t m32[260], uint64_t vdc[52], uint64_t inv[52]);
 
 /* Film::write_image's normalisation (film.rs:236-247) of a raw film
  * {sum of w*L (rgb), sum of w}: rgb = max(0, sum * (1 / weight)) where the weight

@@ -45,6 +45,9 @@ int orc_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t
  * normalisation (film.rs:236-247). */
 void orc_camera_sample_test(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, float u[5]);
 int orc_filter_table(const rt_filter *filter, float out[256]);
+/* the Sobol' tables the camera sampler uses for a width x height frame (data/src/sobol.rs) */
+void orc_sobol_tables(uint32_t width, uint32_t height, uint32_t m32[5 * 52], uint64_t vdc[52], uint64_t inv[52]);
+int orc_sampler_check(const rt_render_opts *opts);
 void orc_film_resolve(float *rgba, uint32_t width, uint32_t height);
 int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
                float *rgba_out, rt_stats *stats, int threads);

@@ -302,7 +302,7 @@ int orc_intersect_brute(const orc_scene *s, const rt_ray *rays, size_t n, rt_hit
 
 int orc_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t first_path,
                       size_t n, rt_ray *rays) {
-    if (!cam || !opts || !rays || !opts->spp || !opts->width) return RT_ERR_INVALID;
+    if (!cam || !opts || !rays || !opts->spp || !opts->width || orc_sampler_check(opts)) return RT_ERR_INVALID;
     for (size_t i = 0; i < n; i++) {
         orc_rng rng;
         orc_path_setup(cam, opts, first_path + i, &rng, &rays[i]);
@@ -312,7 +312,7 @@ int orc_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t
 
 int orc_path_radiance(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
                       uint64_t first_path, size_t n, float *rgb, uint32_t *segments) {
-    if (!s || !cam || !opts || !rgb) return RT_ERR_INVALID;
+    if (!s || !cam || !opts || !rgb || !opts->spp || orc_sampler_check(opts)) return RT_ERR_INVALID;
     job j;
     memset(&j, 0, sizeof j);
     j.mode = 3; j.s = s; j.cam = cam; j.opts = opts; j.rad = rgb; j.segs = segments;
@@ -476,7 +476,7 @@ static int render_filtered(const orc_scene *s, const rt_camera *cam, const rt_re
 
 int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
                float *rgba, rt_stats *stats, int threads) {
-    if (!s || !cam || !opts || !rgba || !opts->spp || !opts->width || !opts->height)
+    if (!s || !cam || !opts || !rgba || !opts->spp || !opts->width || !opts->height || orc_sampler_check(opts))
         return RT_ERR_INVALID;
     if (opts->filter.kind != RT_FILTER_NONE) return render_filtered(s, cam, opts, rgba, stats, threads);
     struct timespec t0, t1;

@@ -10,6 +10,7 @@
  * files under test/ (Lambertian / Metallic / Dielectric / DiffuseLight,
  * Solid / Checker / Image / Noise, Volume) and are specified here.
  */
+#include <stdlib.h>
 #include "orc_internal.h"
 
 #define G3 orc_gamma(3)
@@ -124,7 +125,7 @@ static float radical_inverse(uint32_t base, uint64_t num) { /* low_discrepancy.r
         num = next;
     }
     float v = (float)(double)digits * inv_base_n;
-    return v < 0.99999994f ? v : 0.99999994f;
+    return v < 1.0f - ORC_EPS ? v : 1.0f - ORC_EPS; /* T::ONE_MINUS_EPSILON, number.rs:209 */
 }
 
 static float scrambled_radical_inverse(uint32_t base, uint64_t num, const uint8_t *perm) { /* :43-62 */
@@ -137,7 +138,7 @@ static float scrambled_radical_inverse(uint32_t base, uint64_t num, const uint8_
         num = next;
     }
     float v = inv_base_n * ((float)(double)digits + inv * (float)perm[0] / (1.0f - inv));
-    return v < 0.99999994f ? v : 0.99999994f;
+    return v < 1.0f - ORC_EPS ? v : 1.0f - ORC_EPS; /* T::ONE_MINUS_EPSILON, number.rs:209 */
 }
 
 static uint64_t inverse_radical_inverse(uint32_t base, uint64_t inverse, uint32_t n_digits) { /* :31-40 */
@@ -188,15 +189,260 @@ static void halton_sample(const rt_render_opts *o, uint32_t px, uint32_t py, uin
     u[4] = scrambled_radical_inverse(11, index, g_perm + kPrimeSum[4]);
 }
 
+/* ---- Sobol' camera samples: colour/src/samplers/sobol.rs --------------------------------
+ * The tables of data/src/sobol.rs are not stored here but derived: the generator matrices
+ * of dimensions 0-4 from the Joe-Kuo direction numbers the file names as its source
+ * (data/src/sobol.rs:57-63; 52-bit columns, MATRICES_32 keeps the top 32 bits), and the
+ * two pixel-interval matrices (MATRICES / MATRICES_INV) from dimensions 0 and 1 by linear
+ * algebra over GF(2): with resolution 2^m the top m bits of dimension 0 and of dimension 1
+ * are the pixel (x, y); T maps an index to (x << m) | y.  MATRICES_INV[m-1] is the inverse
+ * of T on the low 2m index bits and MATRICES[m-1][c] = T(1 << (2m + c)).
+ * Deviations from the literal text, following pbrt-v3/v4: b = ((x << m) | y) ^ delta
+ * (sobol.rs:58-59 xors delta into y only); a 1x1 frame uses the sample number as index
+ * (sobol.rs:38-40 returns 0 for every sample); dimensions 0,1 / 2 / 3,4 feed film, time
+ * and lens (global_sampler.rs:121-134 starts a 2D sample one dimension late). */
+static const struct { uint32_t s, a, m[3]; } kJoeKuo[5] = {
+    {0, 0, {0, 0, 0}}, {1, 0, {1, 0, 0}}, {2, 1, {1, 3, 0}}, {3, 1, {1, 3, 1}}, {3, 2, {1, 1, 1}}};
+
+typedef struct {
+    uint32_t m32[5][52]; /* MATRICES_32, dimensions 0-4 */
+    uint64_t vdc[52];    /* MATRICES[m - 1]             */
+    uint64_t inv[52];    /* MATRICES_INV[m - 1]         */
+    uint32_t m;          /* log2 of the resolution      */
+} sobol_tables;
+
+static void sobol_matrices(uint32_t m32[5][52]) {
+    for (int d = 0; d < 5; d++) {
+        uint64_t mk[52];
+        uint32_t s = kJoeKuo[d].s, a = kJoeKuo[d].a;
+        for (uint32_t k = 0; k < 52; k++) {
+            if (s == 0) mk[k] = 1; /* van der Corput */
+            else if (k < s) mk[k] = kJoeKuo[d].m[k];
+            else {
+                uint64_t v = mk[k - s] ^ (mk[k - s] << s);
+                for (uint32_t i = 1; i < s; i++)
+                    if ((a >> (s - 1 - i)) & 1u) v ^= mk[k - i] << i;
+                mk[k] = v;
+            }
+            m32[d][k] = (uint32_t)((mk[k] << (51 - k)) >> 20);
+        }
+    }
+}
+
+static uint64_t sobol_pixel_bits(const uint32_t m32[5][52], uint32_t j, uint32_t m) {
+    return ((uint64_t)(m32[0][j] >> (32 - m)) << m) | (uint64_t)(m32[1][j] >> (32 - m));
+}
+
+static void sobol_setup(uint32_t width, uint32_t height, sobol_tables *t) {
+    memset(t, 0, sizeof *t);
+    sobol_matrices(t->m32);
+    uint32_t res = width > height ? width : height, m = 0;
+    while ((1u << m) < res) m++; /* round_up_pow_2 + log2usize, sobol.rs:15-21 */
+    t->m = m;
+    if (m == 0) return;
+    uint32_t n = 2 * m;
+    uint64_t img[52], pre[52];
+    for (uint32_t j = 0; j < n; j++) { img[j] = sobol_pixel_bits(t->m32, j, m); pre[j] = 1ull << j; }
+    int used[52] = {0};
+    for (uint32_t c = 0; c < n; c++) { /* Gauss-Jordan: afterwards img[r] = 1 << c for one row r */
+        uint32_t r = 0;
+        while (r < n && (used[r] || !((img[r] >> c) & 1u))) r++;
+        used[r] = 1; /* T is invertible, so a row always exists */
+        for (uint32_t i = 0; i < n; i++)
+            if (i != r && ((img[i] >> c) & 1u)) { img[i] ^= img[r]; pre[i] ^= pre[r]; }
+    }
+    for (uint32_t r = 0; r < n; r++)
+        for (uint32_t c = 0; c < n; c++)
+            if (img[r] == (1ull << c)) t->inv[c] = pre[r];
+    for (uint32_t c = 0; 2 * m + c < 52; c++) t->vdc[c] = sobol_pixel_bits(t->m32, 2 * m + c, m);
+}
+
+static float sobol_f32(const sobol_tables *t, uint64_t index, int dim) { /* sobol.rs:111-129 */
+    uint32_t v = 0;
+    for (int i = 0; index; i++, index >>= 1)
+        if (index & 1u) v ^= t->m32[dim][i];
+    float f = (float)v * 2.3283064365386963e-10f;
+    return f < 1.0f - ORC_EPS ? f : 1.0f - ORC_EPS;
+}
+
+static void sobol_sample(const rt_render_opts *o, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
+    static __thread sobol_tables t;
+    static __thread uint32_t tw, th;
+    if (tw != o->width || th != o->height) { sobol_setup(o->width, o->height, &t); tw = o->width; th = o->height; }
+    uint64_t index = s;
+    if (t.m) { /* get_index_for_sample, sobol.rs:31-74 */
+        uint64_t delta = 0, frame = s;
+        for (int c = 0; frame; frame >>= 1, c++)
+            if (frame & 1u) delta ^= t.vdc[c];
+        uint64_t b = (((uint64_t)px << t.m) | py) ^ delta;
+        index = (uint64_t)s << (2 * t.m);
+        for (int c = 0; b; b >>= 1, c++)
+            if (b & 1u) index ^= t.inv[c];
+    }
+    const float res = (float)(1u << t.m), pix[2] = {(float)px, (float)py};
+    for (int k = 0; k < 5; k++) u[k] = sobol_f32(&t, index, k);
+    for (int k = 0; k < 2; k++) { /* sample_dimension, sobol.rs:88-92 */
+        float v = u[k] * res + 0.0f - pix[k];
+        v = v < 0.0f ? 0.0f : v;
+        u[k] = v < 1.0f - ORC_EPS ? v : 1.0f - ORC_EPS;
+    }
+}
+
+void orc_sobol_tables(uint32_t width, uint32_t height, uint32_t m32[5 * 52], uint64_t vdc[52], uint64_t inv[52]) {
+    sobol_tables t;
+    sobol_setup(width, height, &t);
+    memcpy(m32, t.m32, sizeof t.m32);
+    memcpy(vdc, t.vdc, sizeof t.vdc);
+    memcpy(inv, t.inv, sizeof t.inv);
+}
+
+/* ---- pixel samplers: colour/src/samplers/{pixel_sampler,zero_two,stratified}.rs ----------
+ * A PixelSampler makes all samples of a pixel in start_pixel from its own generator.  The
+ * reference keeps one generator per sampler clone, so a pixel's samples depend on every
+ * pixel rendered before it; here the generator is reseeded per pixel
+ * (sequence = 2^63 | (seed * 2^32 + pixel)), which makes pixels independent.  Four sampled
+ * dimensions (pbrt's default); the camera uses 1D dimension 0 (time) and 2D dimensions 0
+ * (film) and 1 (lens), the rest only advance the generator.
+ * buf: film x, film y, time, lens u, lens v, each `spp` floats. */
+#define PIXEL_SAMPLER_DIMS 4
+
+static void shuffle1(orc_rng *rng, float *a, uint32_t n) { /* shuffle_dims(.., 1), rng.rs:77-84 */
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t other = i + orc_rng_limit(rng, n - i);
+        if (a) { float t = a[i]; a[i] = a[other]; a[other] = t; }
+    }
+}
+static void shuffle2(orc_rng *rng, float *a, float *b, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t other = i + orc_rng_limit(rng, n - i);
+        if (a) {
+            float t = a[i]; a[i] = a[other]; a[other] = t;
+            t = b[i]; b[i] = b[other]; b[other] = t;
+        }
+    }
+}
+static float u32_to_unit(uint32_t v) {
+    float f = (float)v * 2.3283064365386963e-10f;
+    return f < 1.0f - ORC_EPS ? f : 1.0f - ORC_EPS;
+}
+
+/* van_der_corput(1, n, ..), zero_two.rs:68-92; out may be NULL (generator advanced only) */
+static void zero_two_1d(orc_rng *rng, float *out, uint32_t n) {
+    uint32_t v = orc_rng_u32(rng);
+    for (uint32_t i = 0; i < n; i++) { /* sample_gray_code, zero_two.rs:129-136 */
+        if (out) out[i] = u32_to_unit(v);
+        v ^= 0x80000000u >> __builtin_ctz(i + 1);
+    }
+    for (uint32_t i = 0; i < n; i++) (void)orc_rng_limit(rng, 1); /* one-element shuffles, :86-89 */
+    shuffle1(rng, out, n);
+}
+/* second generator matrix of the (0,2) sequence (zero_two.rs:106-112): column c is row c
+ * of Pascal's triangle mod 2, most significant bit first */
+static uint32_t sobol2_column(uint32_t c) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k <= c; k++)
+        if ((c & k) == k) v |= 0x80000000u >> k;
+    return v;
+}
+/* sobol_2d(1, n, ..), zero_two.rs:95-126 */
+static void zero_two_2d(orc_rng *rng, float *x, float *y, uint32_t n) {
+    uint32_t vx = orc_rng_u32(rng), vy = orc_rng_u32(rng);
+    for (uint32_t i = 0; i < n; i++) { /* sample_gray_code2, zero_two.rs:140-155 */
+        if (x) { x[i] = u32_to_unit(vx); y[i] = u32_to_unit(vy); }
+        uint32_t c = (uint32_t)__builtin_ctz(i + 1);
+        vx ^= 0x80000000u >> c;
+        vy ^= sobol2_column(c);
+    }
+    for (uint32_t i = 0; i < n; i++) (void)orc_rng_limit(rng, 1);
+    shuffle2(rng, x, y, n);
+}
+
+/* stratified_sample_one + shuffle, stratified.rs:35-38,81-88 */
+static void stratified_1d(orc_rng *rng, float *out, uint32_t n, int jitter) {
+    float inv = 1.0f / (float)(int32_t)n;
+    for (uint32_t i = 0; i < n; i++) {
+        float delta = jitter ? orc_rng_f(rng) : 0.5f;
+        float v = ((float)(int32_t)i + delta) * inv;
+        if (out) out[i] = v < 1.0f - ORC_EPS ? v : 1.0f - ORC_EPS;
+    }
+    shuffle1(rng, out, n);
+}
+/* stratified_sample_two + shuffle, stratified.rs:40-49,91-116; the strata are the nx x ny
+ * grid cells as in pbrt (stratified.rs:111-114 uses the linear index on both axes) */
+static void stratified_2d(orc_rng *rng, float *x, float *y, uint32_t nx, uint32_t ny, int jitter) {
+    float dx = 1.0f / (float)(int32_t)nx, dy = 1.0f / (float)(int32_t)ny;
+    for (uint32_t iy = 0, i = 0; iy < ny; iy++)
+        for (uint32_t ix = 0; ix < nx; ix++, i++) {
+            float jx = jitter ? orc_rng_f(rng) : 0.5f;
+            float jy = jitter ? orc_rng_f(rng) : 0.5f;
+            float vx = ((float)(int32_t)ix + jx) * dx, vy = ((float)(int32_t)iy + jy) * dy;
+            if (x) {
+                x[i] = vx < 1.0f - ORC_EPS ? vx : 1.0f - ORC_EPS;
+                y[i] = vy < 1.0f - ORC_EPS ? vy : 1.0f - ORC_EPS;
+            }
+        }
+    shuffle2(rng, x, y, nx * ny);
+}
+
+static void pixel_samples(const rt_render_opts *o, uint64_t pixel, float *buf) {
+    const uint32_t n = o->spp;
+    orc_rng rng;
+    orc_rng_seq(&rng, (1ull << 63) | ((o->seed << 32) + pixel));
+    float *fx = buf, *fy = buf + n, *time = buf + 2 * (size_t)n, *lu = buf + 3 * (size_t)n, *lv = buf + 4 * (size_t)n;
+    if (o->sampler == RT_SAMPLER_ZERO_TWO) {
+        for (int d = 0; d < PIXEL_SAMPLER_DIMS; d++) zero_two_1d(&rng, d == 0 ? time : NULL, n);
+        zero_two_2d(&rng, fx, fy, n);
+        zero_two_2d(&rng, lu, lv, n);
+    } else {
+        const uint32_t nx = o->sampler_arg & 0xffffu, ny = n / nx;
+        const int jitter = !(o->sampler_arg & RT_STRATIFIED_NO_JITTER);
+        for (int d = 0; d < PIXEL_SAMPLER_DIMS; d++) stratified_1d(&rng, d == 0 ? time : NULL, n, jitter);
+        stratified_2d(&rng, fx, fy, nx, ny, jitter);
+        stratified_2d(&rng, lu, lv, nx, ny, jitter);
+    }
+}
+
+static void pixel_sampler_sample(const rt_render_opts *o, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
+    static __thread struct { float *buf; uint32_t cap; uint64_t pixel, seed; uint32_t sampler, arg, spp, width, valid; } c;
+    const uint64_t pixel = (uint64_t)py * o->width + px;
+    if (!c.valid || c.pixel != pixel || c.seed != o->seed || c.sampler != o->sampler || c.arg != o->sampler_arg ||
+        c.spp != o->spp || c.width != o->width) {
+        if (c.cap < o->spp) {
+            free(c.buf);
+            c.buf = (float *)malloc((size_t)o->spp * 5 * sizeof(float));
+            c.cap = o->spp;
+        }
+        pixel_samples(o, pixel, c.buf);
+        c.pixel = pixel; c.seed = o->seed; c.sampler = o->sampler; c.arg = o->sampler_arg;
+        c.spp = o->spp; c.width = o->width; c.valid = 1;
+    }
+    for (int k = 0; k < 5; k++) u[k] = c.buf[(size_t)k * o->spp + s];
+}
+
+/* 0 when the options name a sampler and arguments the samplers accept */
+int orc_sampler_check(const rt_render_opts *o) {
+    if (o->sampler > RT_SAMPLER_STRATIFIED) return -1;
+    if (o->sampler == RT_SAMPLER_ZERO_TWO && (o->spp & (o->spp - 1))) return -1;
+    if (o->sampler == RT_SAMPLER_STRATIFIED) {
+        uint32_t nx = o->sampler_arg & 0xffffu;
+        if (!nx || o->spp % nx) return -1;
+    }
+    return 0;
+}
+
 void orc_camera_sample(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, orc_rng *rng, float u[5]) {
     if (opts->sampler == RT_SAMPLER_HALTON) {
         halton_sample(opts, px, py, s, u);
+    } else if (opts->sampler == RT_SAMPLER_SOBOL) {
+        sobol_sample(opts, px, py, s, u);
+    } else if (opts->sampler == RT_SAMPLER_ZERO_TWO || opts->sampler == RT_SAMPLER_STRATIFIED) {
+        pixel_sampler_sample(opts, px, py, s, u);
     } else {
         for (int k = 0; k < 5; k++) u[k] = orc_rng_f(rng);
     }
 }
 
-/* known-answer hook for the tests: the camera sample without a generator (Halton only) */
+/* known-answer hook for the tests: the camera sample of a sampler that draws nothing from the path's generator */
 void orc_camera_sample_test(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
     orc_rng rng = {0, 1};
     orc_camera_sample(opts, px, py, s, &rng, u);

@@ -100,10 +100,11 @@ class rt_render_opts(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("max_depth", C.c_uint32), ("seed", C.c_uint64), ("shard_index", C.c_uint32),
                 ("shard_count", C.c_uint32), ("max_paths", C.c_uint32), ("flags", C.c_uint32),
-                ("filter", rt_filter), ("sampler", C.c_uint32), ("_pad", C.c_uint32)]
+                ("filter", rt_filter), ("sampler", C.c_uint32), ("sampler_arg", C.c_uint32)]
 
 
-RT_SAMPLER_RANDOM, RT_SAMPLER_HALTON = 0, 1
+RT_SAMPLER_RANDOM, RT_SAMPLER_HALTON, RT_SAMPLER_SOBOL, RT_SAMPLER_ZERO_TWO, RT_SAMPLER_STRATIFIED = range(5)
+RT_STRATIFIED_NO_JITTER = 0x80000000
 
 
 class rt_stats(C.Structure):
@@ -133,7 +134,7 @@ EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_world_bound", "rt_scene_get_info",
     "rt_scene_get_nodes", "rt_scene_get_prim_order", "rt_scene_upload", "rt_intersect",
     "rt_intersect_dev", "rt_intersect_count", "rt_occluded", "rt_occluded_dev",
-    "rt_generate_rays", "rt_render", "rt_render_dev", "rt_filter_table", "rt_film_resolve_dev",
+    "rt_generate_rays", "rt_render", "rt_render_dev", "rt_filter_table", "rt_sobol_tables", "rt_film_resolve_dev",
     "rt_last_error", "rt_abi_sizes",
 ]
 

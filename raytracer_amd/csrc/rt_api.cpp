@@ -96,6 +96,9 @@ struct DeviceBuffers {
     float4 *radiance = nullptr;
     uint32_t *counts = nullptr;
     std::vector<void *> ws_allocs;
+    // tables or per-pixel samples of the camera sampler (grown on demand)
+    void *sampler_mem = nullptr;
+    size_t sampler_bytes = 0;
 };
 
 } // namespace
@@ -249,6 +252,55 @@ void release(DeviceBuffers &db) {
     for (void *p : db.ws_allocs) (void)hipFree(p);
     db.allocs.clear();
     db.ws_allocs.clear();
+    if (db.sampler_mem) (void)hipFree(db.sampler_mem);
+    db.sampler_mem = nullptr;
+    db.sampler_bytes = 0;
+}
+
+// 0, or the reason the sampler options are not accepted (Stratified::new / ZeroTwo::new arguments)
+const char *sampler_problem(const rt_render_opts &o) {
+    if (o.sampler > RT_SAMPLER_STRATIFIED) return "unknown sampler";
+    if (o.sampler == RT_SAMPLER_ZERO_TWO && (o.spp & (o.spp - 1)))
+        return "the (0,2) sampler needs a power-of-two spp (ZeroTwo::new rounds up: pass the rounded count)";
+    if (o.sampler == RT_SAMPLER_STRATIFIED) {
+        const uint32_t nx = o.sampler_arg & 0xffffu;
+        if (!nx || o.spp % nx) return "stratified sampler: sampler_arg's x strata must divide spp";
+    }
+    return nullptr;
+}
+
+// Device memory the frame's camera sampler reads, filled on `stream`: the Sobol' tables, or
+// every sample of n_slots pixels for the pixel samplers.  `mem`/`bytes` is a grow-only block.
+int sampler_prepare(rt::FrameDev &F, uint32_t n_slots, bool by_rank, uint64_t first_pixel, void **mem, size_t *bytes,
+                    hipStream_t stream) {
+    size_t need = 0;
+    if (F.sampler == RT_SAMPLER_SOBOL) need = sizeof(rt::SobolDev);
+    else if (F.sampler == RT_SAMPLER_ZERO_TWO || F.sampler == RT_SAMPLER_STRATIFIED)
+        need = (size_t)n_slots * F.spp * 5 * sizeof(float);
+    if (!need) return RT_OK;
+    if ((uint64_t)n_slots * F.spp >= (1ull << 32)) return fail(RT_ERR_LIMIT, "too many camera samples");
+    if (need > *bytes) {
+        if (*mem) (void)hipFree(*mem);
+        *mem = nullptr;
+        *bytes = 0;
+        if (hipMalloc(mem, need) != hipSuccess) {
+            *mem = nullptr;
+            return fail(RT_ERR_NOMEM, "no device memory for %zu bytes of camera samples", need);
+        }
+        *bytes = need;
+    }
+    if (F.sampler == RT_SAMPLER_SOBOL) {
+        rt::SobolDev t;
+        F.sobol_log2 = rt::sobol_setup(F.width, F.height, t);
+        HIP_TRY(hipMemcpyAsync(*mem, &t, sizeof t, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream)); // t leaves scope
+        F.sobol = static_cast<const rt::SobolDev *>(*mem);
+    } else {
+        F.sample_stride = n_slots * F.spp;
+        F.pixel_samples = static_cast<const float *>(*mem);
+        HIP_TRY(rt::launch_pixel_samples(F, n_slots, by_rank, first_pixel, static_cast<float *>(*mem), stream));
+    }
+    return RT_OK;
 }
 
 // Lays the scene out for the kernels: one 64-byte record per interior node with
@@ -751,21 +803,97 @@ int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t 
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
         return fail(RT_ERR_NO_DEVICE, "device %d not available; librt355 has no CPU path", device);
     if (n > kChunk) return fail(RT_ERR_LIMIT, "at most %zu rays per call", kChunk);
+    if (const char *why = sampler_problem(*opts)) return fail(RT_ERR_INVALID, "%s", why);
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(device));
     rt_ray *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, n * sizeof(rt_ray)));
-    rt::FrameDev F{opts->width, opts->height, opts->spp, (opts->width + 31) / 32, 0, 1, opts->seed, opts->sampler, {}};
+    rt::FrameDev F{};
+    F.width = opts->width;
+    F.height = opts->height;
+    F.spp = opts->spp;
+    F.tiles_x = (opts->width + 31) / 32;
+    F.shard_count = 1;
+    F.seed = opts->seed;
+    F.sampler = opts->sampler;
+    F.sampler_arg = opts->sampler_arg;
     if (opts->sampler == RT_SAMPLER_HALTON) rt::halton_setup(opts->width, opts->height, F.halton);
+    void *smem = nullptr;
+    size_t sbytes = 0;
+    const uint64_t first_pixel = first_path / opts->spp, last_pixel = (first_path + n - 1) / opts->spp;
+    int rc = sampler_prepare(F, (uint32_t)(last_pixel - first_pixel + 1), false, first_pixel, &smem, &sbytes, nullptr);
+    if (rc != RT_OK) {
+        (void)hipFree(d);
+        if (smem) (void)hipFree(smem);
+        return rc;
+    }
     hipError_t e = rt::launch_generate_rays(F, *cam, first_path, (uint32_t)n, d, nullptr);
     if (e == hipSuccess) e = hipMemcpy(rays, d, n * sizeof(rt_ray), hipMemcpyDeviceToHost);
     (void)hipFree(d);
+    if (smem) (void)hipFree(smem);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "ray generation failed: %s", hipGetErrorString(e));
     return RT_OK;
 }
 
 extern "C++" {
 namespace rt {
+
+// The tables of data/src/sobol.rs for one frame, computed instead of stored.  Generator
+// matrices of dimensions 0-4 come from the Joe-Kuo direction numbers the file cites
+// (data/src/sobol.rs:57-63): column k of a dimension with primitive polynomial of degree s
+// and coefficients a is m_k * 2^(51-k), m_k = m_(k-s) ^ 2^s m_(k-s) ^ sum a_i 2^i m_(k-i);
+// MATRICES_32 keeps the top 32 of the 52 bits.  With resolution 2^m, T(index) = (x << m) | y
+// where x, y are the top m bits of dimensions 0 and 1; MATRICES_INV[m-1] inverts T on index
+// bits 0..2m-1 and MATRICES[m-1][c] = T(2^(2m+c)).
+uint32_t sobol_setup(uint32_t width, uint32_t height, SobolDev &t) {
+    struct Poly { uint32_t s, a; uint64_t m[3]; };
+    static const Poly poly[5] = {{0, 0, {0, 0, 0}}, {1, 0, {1, 0, 0}}, {2, 1, {1, 3, 0}}, {3, 1, {1, 3, 1}}, {3, 2, {1, 1, 1}}};
+    memset(&t, 0, sizeof t);
+    for (int d = 0; d < 5; d++) {
+        std::vector<uint64_t> mk(52, 1); // degree 0: van der Corput, every m_k = 1
+        const Poly &p = poly[d];
+        for (uint32_t k = 0; k < 52 && p.s; k++) {
+            if (k < p.s) {
+                mk[k] = p.m[k];
+                continue;
+            }
+            uint64_t v = mk[k - p.s] ^ (mk[k - p.s] << p.s);
+            for (uint32_t i = 1; i < p.s; i++)
+                if ((p.a >> (p.s - 1 - i)) & 1u) v ^= mk[k - i] << i;
+            mk[k] = v;
+        }
+        for (uint32_t k = 0; k < 52; k++) t.m32[d][k] = (uint32_t)((mk[k] << (51 - k)) >> 20);
+    }
+    uint32_t m = 0;
+    while ((1u << m) < std::max(width, height)) m++; // round_up_pow_2 + log2usize, sobol.rs:15-21
+    if (m == 0) return 0;
+    auto T = [&](uint32_t j) {
+        return ((uint64_t)(t.m32[0][j] >> (32 - m)) << m) | (uint64_t)(t.m32[1][j] >> (32 - m));
+    };
+    // Gauss-Jordan over GF(2) on the pairs (T(2^j), 2^j), j < 2m
+    const uint32_t n = 2 * m;
+    std::vector<uint64_t> image(n), source(n);
+    std::vector<bool> pivot(n, false);
+    for (uint32_t j = 0; j < n; j++) {
+        image[j] = T(j);
+        source[j] = 1ull << j;
+    }
+    for (uint32_t c = 0; c < n; c++) {
+        uint32_t r = 0;
+        while (r < n && (pivot[r] || !((image[r] >> c) & 1u))) r++;
+        if (r == n) return m; // cannot happen: T is invertible on these bits
+        pivot[r] = true;
+        for (uint32_t i = 0; i < n; i++)
+            if (i != r && ((image[i] >> c) & 1u)) {
+                image[i] ^= image[r];
+                source[i] ^= source[r];
+            }
+        t.inv[c] = 0;
+    }
+    for (uint32_t r = 0; r < n; r++) t.inv[__builtin_ctzll(image[r])] = source[r];
+    for (uint32_t c = 0; 2 * m + c < 52; c++) t.vdc[c] = T(2 * m + c);
+    return m;
+}
 
 // Halton::new, colour/src/samplers/halton.rs:25-52, and the permutation table of
 // data/src/lib.rs:16-41 (digits of each prime shuffled by one Rng::default() stream).
@@ -881,6 +1009,16 @@ int rt_filter_table(const rt_filter *f, float out[256]) {
     return RT_OK;
 }
 
+int rt_sobol_tables(uint32_t width, uint32_t height, uint32_t m32[260], uint64_t vdc[52], uint64_t inv[52]) {
+    if (!m32 || !vdc || !inv || !width || !height) return fail(RT_ERR_INVALID, "bad argument");
+    rt::SobolDev t;
+    (void)rt::sobol_setup(width, height, t);
+    memcpy(m32, t.m32, sizeof t.m32);
+    memcpy(vdc, t.vdc, sizeof t.vdc);
+    memcpy(inv, t.inv, sizeof t.inv);
+    return RT_OK;
+}
+
 int rt_film_resolve_dev(float *d_rgba, uint32_t width, uint32_t height, int device, void *stream) {
     if (!d_rgba) return fail(RT_ERR_INVALID, "null argument");
     int count = 0;
@@ -914,9 +1052,17 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     }
     std::lock_guard<std::mutex> g(db->render_lock);
 
-    if (o->sampler > RT_SAMPLER_HALTON) return fail(RT_ERR_INVALID, "unknown sampler");
-    rt::FrameDev F{o->width, o->height, o->spp, (o->width + 31) / 32, o->shard_index, shard_count, o->seed,
-                   o->sampler, {}};
+    if (const char *why = sampler_problem(*o)) return fail(RT_ERR_INVALID, "%s", why);
+    rt::FrameDev F{};
+    F.width = o->width;
+    F.height = o->height;
+    F.spp = o->spp;
+    F.tiles_x = (o->width + 31) / 32;
+    F.shard_index = o->shard_index;
+    F.shard_count = shard_count;
+    F.seed = o->seed;
+    F.sampler = o->sampler;
+    F.sampler_arg = o->sampler_arg;
     if (o->sampler == RT_SAMPLER_HALTON) rt::halton_setup(o->width, o->height, F.halton);
     const uint32_t tiles = F.tiles_x * ((o->height + 31) / 32);
     const uint32_t my_tiles = tiles > o->shard_index ? (tiles - o->shard_index + shard_count - 1) / shard_count : 0;
@@ -936,6 +1082,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     if (batch_paths64 >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard too large for one sample per batch");
     const uint32_t batch_paths = (uint32_t)batch_paths64;
     if ((rc = grow_workspace(*db, batch_paths ? batch_paths : 1, o->max_depth)) != RT_OK) return rc;
+    if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) return rc;
 
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;

@@ -109,6 +109,7 @@ RT_DEV float sel_min(float a, float b) { return a < b ? a : b; } // number.rs:13
 
 // gamma(n) with eps = f32::EPSILON, geometry/src/float.rs:44-46, number.rs:205
 constexpr float kEps = 1.1920928955078125e-7f;
+constexpr float kOneMinusEps = 1.0f - kEps; // ONE_MINUS_EPSILON, geometry/src/number.rs:209
 __host__ __device__ constexpr float gamma_n(int n) {
     return ((float)n * kEps) / (1.0f - (float)n * kEps);
 }

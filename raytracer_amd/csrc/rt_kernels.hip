@@ -609,7 +609,7 @@ RT_DEV float radical_inverse(uint64_t num) { // low_discrepancy.rs:7-21
         inv_base_n *= inv;
         num = next;
     }
-    return sel_min((float)(double)digits * inv_base_n, 0.99999994f);
+    return sel_min((float)(double)digits * inv_base_n, kOneMinusEps);
 }
 template <uint32_t BASE>
 RT_DEV float scrambled_radical_inverse(uint64_t num, const uint8_t *perm) { // low_discrepancy.rs:43-62
@@ -622,7 +622,7 @@ RT_DEV float scrambled_radical_inverse(uint64_t num, const uint8_t *perm) { // l
         inv_base_n *= inv;
         num = next;
     }
-    return sel_min(inv_base_n * ((float)(double)digits + inv * (float)perm[0] / (1.0f - inv)), 0.99999994f);
+    return sel_min(inv_base_n * ((float)(double)digits + inv * (float)perm[0] / (1.0f - inv)), kOneMinusEps);
 }
 template <uint32_t BASE>
 RT_DEV uint64_t inverse_radical_inverse(uint64_t inverse, uint32_t n_digits) { // low_discrepancy.rs:31-40
@@ -653,10 +653,171 @@ RT_DEV void halton_sample(const HaltonDev &h, uint32_t px, uint32_t py, uint32_t
     u[4] = scrambled_radical_inverse<11>(index, h.perm + 17);
 }
 
+// ---- Sobol' camera samples: colour/src/samplers/sobol.rs ---------------------------------------
+RT_DEV float unit_float(uint32_t v) { return sel_min((float)v * 2.3283064365386963e-10f, kOneMinusEps); }
+
+// get_index_for_sample (sobol.rs:31-74, with b = ((x << m) | y) ^ delta as in pbrt) and
+// sample_dimension (sobol.rs:76-95) for dimensions 0-4.  Loop counts are uniform so the
+// table reads are scalar.
+RT_DEV void sobol_sample(const FrameDev &F, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
+    const SobolDev &T = *F.sobol;
+    const uint32_t m = F.sobol_log2;
+    uint64_t index = s;
+    uint32_t sbits = 32u - (uint32_t)__builtin_clz(F.spp | 1u); // sample numbers are below spp
+    if (m) {
+        uint64_t delta = 0;
+        for (uint32_t c = 0; c < sbits && 2 * m + c < 52; c++) delta ^= ((s >> c) & 1u) ? T.vdc[c] : 0ull;
+        const uint64_t b = (((uint64_t)px << m) | py) ^ delta;
+        index = (uint64_t)s << (2 * m);
+        for (uint32_t c = 0; c < 2 * m; c++) index ^= ((b >> c) & 1u) ? T.inv[c] : 0ull;
+    }
+    uint32_t v[5] = {0, 0, 0, 0, 0};
+    const uint32_t nbits = 2 * m + sbits < 52 ? 2 * m + sbits : 52;
+    for (uint32_t c = 0; c < nbits; c++) { // sobol_sample_f32, sobol.rs:111-129
+        const bool on = (index >> c) & 1u;
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] ^= on ? T.m32[k][c] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) u[k] = unit_float(v[k]);
+    const float res = (float)(1u << m);
+    u[0] = sel_min(sel_max(u[0] * res + 0.0f - (float)px, 0.0f), kOneMinusEps);
+    u[1] = sel_min(sel_max(u[1] * res + 0.0f - (float)py, 0.0f), kOneMinusEps);
+}
+
+// ---- pixel samplers: colour/src/samplers/{pixel_sampler,zero_two,stratified}.rs -----------------
+// One thread makes all samples of one pixel, as start_pixel does, from a generator seeded per
+// pixel (sequence 2^63 | (seed * 2^32 + pixel)): four sampled dimensions, of which the camera
+// uses 1D dimension 0 (time) and 2D dimensions 0 (film) and 1 (lens); the others only advance
+// the generator.
+constexpr int kPixelSamplerDims = 4;
+
+RT_DEV uint32_t rng_limit(Rng &rng, uint32_t limit) { // uniform_u32_limit, rng.rs:51-59
+    const uint32_t threshold = (~limit + 1u) % limit;
+    for (;;) {
+        const uint32_t r = rng_u32(rng);
+        if (r >= threshold) return r % limit;
+    }
+}
+RT_DEV void shuffle1(Rng &rng, float *a, uint32_t n) { // shuffle_dims(.., 1), rng.rs:77-84
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t other = i + rng_limit(rng, n - i);
+        if (a) {
+            const float t = a[i];
+            a[i] = a[other];
+            a[other] = t;
+        }
+    }
+}
+RT_DEV void shuffle2(Rng &rng, float *a, float *b, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t other = i + rng_limit(rng, n - i);
+        const float ta = a[i], tb = b[i];
+        a[i] = a[other];
+        b[i] = b[other];
+        a[other] = ta;
+        b[other] = tb;
+    }
+}
+// van_der_corput(1, n, ..), zero_two.rs:68-92
+RT_DEV void zero_two_1d(Rng &rng, float *out, uint32_t n) {
+    uint32_t v = rng_u32(rng);
+    for (uint32_t i = 0; i < n; i++) { // sample_gray_code, zero_two.rs:129-136
+        if (out) out[i] = unit_float(v);
+        v ^= 0x80000000u >> __builtin_ctz(i + 1);
+    }
+    for (uint32_t i = 0; i < n; i++) (void)rng_limit(rng, 1u); // one-element shuffles, zero_two.rs:86-89
+    shuffle1(rng, out, n);
+}
+// column c of the second (0,2) generator matrix (zero_two.rs:106-112): row c of Pascal's
+// triangle mod 2, most significant bit first
+RT_DEV uint32_t sobol2_column(uint32_t c) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k <= c; k++)
+        if ((c & k) == k) v |= 0x80000000u >> k;
+    return v;
+}
+// sobol_2d(1, n, ..), zero_two.rs:95-126
+RT_DEV void zero_two_2d(Rng &rng, float *x, float *y, uint32_t n) {
+    uint32_t vx = rng_u32(rng), vy = rng_u32(rng);
+    for (uint32_t i = 0; i < n; i++) { // sample_gray_code2, zero_two.rs:140-155
+        x[i] = unit_float(vx);
+        y[i] = unit_float(vy);
+        const uint32_t c = (uint32_t)__builtin_ctz(i + 1);
+        vx ^= 0x80000000u >> c;
+        vy ^= sobol2_column(c);
+    }
+    for (uint32_t i = 0; i < n; i++) (void)rng_limit(rng, 1u);
+    shuffle2(rng, x, y, n);
+}
+// stratified_sample_one + shuffle, stratified.rs:35-38,81-88
+RT_DEV void stratified_1d(Rng &rng, float *out, uint32_t n, bool jitter) {
+    const float inv = 1.0f / (float)(int32_t)n;
+    for (uint32_t i = 0; i < n; i++) {
+        const float delta = jitter ? rng_f(rng) : 0.5f;
+        if (out) out[i] = sel_min(((float)(int32_t)i + delta) * inv, kOneMinusEps);
+    }
+    shuffle1(rng, out, n);
+}
+// stratified_sample_two + shuffle, stratified.rs:40-49,91-116, strata = cells of the nx x ny grid
+RT_DEV void stratified_2d(Rng &rng, float *x, float *y, uint32_t nx, uint32_t ny, bool jitter) {
+    const float dx = 1.0f / (float)(int32_t)nx, dy = 1.0f / (float)(int32_t)ny;
+    for (uint32_t iy = 0, i = 0; iy < ny; iy++)
+        for (uint32_t ix = 0; ix < nx; ix++, i++) {
+            const float jx = jitter ? rng_f(rng) : 0.5f;
+            const float jy = jitter ? rng_f(rng) : 0.5f;
+            x[i] = sel_min(((float)(int32_t)ix + jx) * dx, kOneMinusEps);
+            y[i] = sel_min(((float)(int32_t)iy + jy) * dy, kOneMinusEps);
+        }
+    shuffle2(rng, x, y, nx * ny);
+}
+
+RT_DEV bool rank_to_pixel(const FrameDev &F, uint32_t rank, uint32_t &px, uint32_t &py);
+
+__global__ __launch_bounds__(kBlock) void k_pixel_samples(FrameDev F, uint32_t n_slots, int by_rank,
+                                                          uint64_t first_pixel, float *out) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n_slots) return;
+    uint64_t pixel;
+    if (by_rank) {
+        uint32_t px, py;
+        if (!rank_to_pixel(F, slot, px, py)) return;
+        pixel = (uint64_t)py * F.width + px;
+    } else {
+        pixel = first_pixel + slot;
+        if (pixel >= (uint64_t)F.width * F.height) return;
+    }
+    Rng rng;
+    rng_seq(rng, (1ull << 63) | ((F.seed << 32) + pixel));
+    const uint32_t n = F.spp;
+    float *base = out + (size_t)slot * n;
+    float *fx = base, *fy = base + F.sample_stride, *time = base + 2 * (size_t)F.sample_stride;
+    float *lu = base + 3 * (size_t)F.sample_stride, *lv = base + 4 * (size_t)F.sample_stride;
+    if (F.sampler == RT_SAMPLER_ZERO_TWO) {
+        for (int d = 0; d < kPixelSamplerDims; d++) zero_two_1d(rng, d == 0 ? time : nullptr, n);
+        zero_two_2d(rng, fx, fy, n);
+        zero_two_2d(rng, lu, lv, n);
+    } else {
+        const uint32_t nx = F.sampler_arg & 0xffffu, ny = n / nx;
+        const bool jitter = !(F.sampler_arg & RT_STRATIFIED_NO_JITTER);
+        for (int d = 0; d < kPixelSamplerDims; d++) stratified_1d(rng, d == 0 ? time : nullptr, n, jitter);
+        stratified_2d(rng, fx, fy, nx, ny, jitter);
+        stratified_2d(rng, lu, lv, nx, ny, jitter);
+    }
+}
+
 // Camera sample of path (pixel, s): film offsets u[0], u[1], time u[2], lens u[3], u[4].
-RT_DEV void camera_sample(const FrameDev &F, uint32_t px, uint32_t py, uint32_t s, Rng &rng, float u[5]) {
+// slot: the pixel's place in F.pixel_samples (pixel samplers only).
+RT_DEV void camera_sample(const FrameDev &F, uint32_t slot, uint32_t px, uint32_t py, uint32_t s, Rng &rng,
+                          float u[5]) {
     if (F.sampler == RT_SAMPLER_HALTON) {
         halton_sample(F.halton, px, py, s, u);
+    } else if (F.sampler == RT_SAMPLER_SOBOL) {
+        sobol_sample(F, px, py, s, u);
+    } else if (F.sampler == RT_SAMPLER_ZERO_TWO || F.sampler == RT_SAMPLER_STRATIFIED) {
+        const float *p = F.pixel_samples + (size_t)slot * F.spp + s;
+#pragma unroll
+        for (int k = 0; k < 5; k++) u[k] = p[(size_t)k * F.sample_stride];
     } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) u[k] = rng_f(rng);
@@ -665,10 +826,11 @@ RT_DEV void camera_sample(const FrameDev &F, uint32_t px, uint32_t py, uint32_t 
 
 // Path of pixel (px, py), global id `path` = pixel * spp + sample; PCG32 sequence =
 // seed * 2^32 + path; camera sample order: film x, film y, time, lens u, lens v.
-RT_DEV Ray path_setup(const FrameDev &F, const rt_camera &cam, uint32_t px, uint32_t py, uint64_t path, Rng &rng) {
+RT_DEV Ray path_setup(const FrameDev &F, const rt_camera &cam, uint32_t slot, uint32_t px, uint32_t py,
+                      uint64_t path, Rng &rng) {
     rng_seq(rng, (F.seed << 32) + path);
     float u[5];
-    camera_sample(F, px, py, (uint32_t)(path % F.spp), rng, u);
+    camera_sample(F, slot, px, py, (uint32_t)(path % F.spp), rng, u);
     return camera_ray(cam, (float)px + u[0], (float)py + u[1], u[3], u[4], u[2]);
 }
 
@@ -678,7 +840,8 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(FrameDev F, rt_camera 
     if (i >= n) return;
     Rng rng;
     uint64_t path = first + i, pixel = path / F.spp;
-    Ray r = path_setup(F, cam, (uint32_t)(pixel % F.width), (uint32_t)(pixel / F.width), path, rng);
+    Ray r = path_setup(F, cam, (uint32_t)(pixel - first / F.spp), (uint32_t)(pixel % F.width),
+                       (uint32_t)(pixel / F.width), path, rng);
     float4 *o = reinterpret_cast<float4 *>(rays + i);
     o[0] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
     o[1] = make_float4(r.d.y, r.d.z, r.t_max, r.time);
@@ -724,7 +887,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, 
         uint32_t rank = local / s_count, s = s0 + local % s_count, px, py;
         if (rank_to_pixel(F, rank, px, py)) {
             gpath = (py * F.width + px) * F.spp + s;
-            ray = path_setup(F, cam, px, py, gpath, rng);
+            ray = path_setup(F, cam, rank, px, py, gpath, rng);
             alive = true;
         }
     }
@@ -1189,7 +1352,7 @@ __global__ __launch_bounds__(kBlock) void k_film(FrameDev F, FilterDev T, const 
                 Rng rng;
                 float u[5];
                 rng_seq(rng, (F.seed << 32) + path);
-                camera_sample(F, (uint32_t)qx, (uint32_t)qy, s0 + k, rng, u);
+                camera_sample(F, rank, (uint32_t)qx, (uint32_t)qy, s0 + k, rng, u);
                 const float dx = ((float)qx + u[0]) - 0.5f, dy = ((float)qy + u[1]) - 0.5f;
                 if (fxp < ceilf(dx - T.rx) || fxp > floorf(dx + T.rx)) continue;
                 if (fyp < ceilf(dy - T.ry) || fyp > floorf(dy + T.ry)) continue;
@@ -1269,6 +1432,14 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out);
     else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pixel_samples(const FrameDev &F, uint32_t n_slots, bool by_rank, uint64_t first_pixel, float *out,
+                                hipStream_t stream) {
+    if (!n_slots) return hipSuccess;
+    hipLaunchKernelGGL(k_pixel_samples, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, n_slots,
+                       by_rank ? 1 : 0, first_pixel, out);
     return hipGetLastError();
 }
 

@@ -37,17 +37,41 @@ struct HaltonDev {
     uint8_t perm[28];     // by prime: 2, 3, 5, 7, 11 at offsets 0, 2, 5, 10, 17
 };
 
+// Sobol::new (colour/src/samplers/sobol.rs:14-25) for one frame size: the generator matrices
+// of dimensions 0-4 (MATRICES_32, data/src/sobol.rs:68) and the two pixel-interval matrices
+// of the frame's resolution 2^m (MATRICES[m-1], MATRICES_INV[m-1], data/src/sobol.rs:59978,
+// 60151).  Lives in device memory.
+struct SobolDev {
+    uint32_t m32[5][52];
+    uint64_t vdc[52];
+    uint64_t inv[52];
+};
+
 struct FrameDev {
     uint32_t width, height, spp;
     uint32_t tiles_x;
     uint32_t shard_index, shard_count;
     uint64_t seed;
-    uint32_t sampler; // rt_sampler_kind
+    uint32_t sampler;     // rt_sampler_kind
+    uint32_t sampler_arg; // rt_render_opts::sampler_arg
     HaltonDev halton;
+    const SobolDev *sobol; // RT_SAMPLER_SOBOL
+    uint32_t sobol_log2;   // m
+    // RT_SAMPLER_ZERO_TWO / RT_SAMPLER_STRATIFIED: the camera samples of every pixel, made by
+    // launch_pixel_samples before the first ray: five arrays (film x, film y, time, lens u,
+    // lens v) of sample_stride floats, sample s of pixel slot p at p * spp + s
+    uint32_t sample_stride;
+    const float *pixel_samples;
 };
 
 // Fills `h` for a width x height frame (host).
 void halton_setup(uint32_t width, uint32_t height, HaltonDev &h);
+// Fills `t` for a width x height frame (host); returns m = log2 of the resolution.
+uint32_t sobol_setup(uint32_t width, uint32_t height, SobolDev &t);
+// PixelSamplerImpl::start_pixel for n_slots pixels (zero_two.rs:23-60, stratified.rs:34-77).
+// by_rank: slot = the shard's pixel rank (32x32 tiles); else slot = pixel - first_pixel.
+hipError_t launch_pixel_samples(const FrameDev &F, uint32_t n_slots, bool by_rank, uint64_t first_pixel, float *out,
+                                hipStream_t stream);
 
 // How the trace kernels are launched for one scene on one device.
 struct LaunchShape {
@@ -65,6 +89,7 @@ hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ra
                             rt_hit *hits, unsigned long long *counters, hipStream_t stream);
 hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
                            hipStream_t stream);
+// pixel samplers: F.pixel_samples holds the pixels first / spp ... (slot = pixel - first / spp)
 hipError_t launch_generate_rays(const FrameDev &F, const rt_camera &cam, uint64_t first, uint32_t n,
                                 rt_ray *rays, hipStream_t stream);
 hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,

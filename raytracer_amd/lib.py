@@ -58,9 +58,9 @@ def make_filter(kind=abi.RT_FILTER_NONE, radius=(0.5, 0.5), a=0.0, b=0.0):
 
 
 def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0, filter=None,
-                sampler=0):
+                sampler=0, sampler_arg=0):
     return abi.rt_render_opts(width, height, spp, max_depth, seed, shard[0], shard[1], max_paths,
-                              flags, filter if filter is not None else abi.rt_filter(), sampler, 0)
+                              flags, filter if filter is not None else abi.rt_filter(), sampler, sampler_arg)
 
 
 def filter_table(filt):
@@ -68,6 +68,16 @@ def filter_table(filt):
     out = np.zeros(256, dtype=np.float32)
     check(load().rt_filter_table(C.byref(filt), out.ctypes.data))
     return out.reshape(16, 16)
+
+
+def sobol_tables(width, height):
+    """(MATRICES_32[:5*52], MATRICES[m-1], MATRICES_INV[m-1]) of data/src/sobol.rs for a frame."""
+    m32 = np.zeros(260, dtype=np.uint32)
+    vdc = np.zeros(52, dtype=np.uint64)
+    inv = np.zeros(52, dtype=np.uint64)
+    check(load().rt_sobol_tables(C.c_uint32(width), C.c_uint32(height), C.c_void_p(m32.ctypes.data),
+                                 C.c_void_p(vdc.ctypes.data), C.c_void_p(inv.ctypes.data)))
+    return m32.reshape(5, 52), vdc, inv
 
 
 def film_resolve_dev(rgba_ptr, width, height, device=0, stream=None):

@@ -72,9 +72,9 @@ def make_opts(max_prims=4, split=abi.RT_SPLIT_SAH):
 
 
 def render_opts(width, height, spp, max_depth=50, seed=0, shard=(0, 1), max_paths=0, flags=0, filter=None,
-                sampler=0):
+                sampler=0, sampler_arg=0):
     return abi.rt_render_opts(width, height, spp, max_depth, seed, shard[0], shard[1], max_paths,
-                              flags, filter if filter is not None else abi.rt_filter(), sampler, 0)
+                              flags, filter if filter is not None else abi.rt_filter(), sampler, sampler_arg)
 
 
 def filter_table(filt):

@@ -31,10 +31,15 @@ def main():
     ap.add_argument("--spp-scale", type=float, default=1.0)
     ap.add_argument("--check", type=int, default=64, help="pixels compared with the oracle")
     ap.add_argument("--split", type=int, default=abi.RT_SPLIT_SAH)
+    ap.add_argument("--sampler", default="random", choices=["random", "halton", "sobol", "zero_two", "stratified"])
     args = ap.parse_args()
+    sampler = ["random", "halton", "sobol", "zero_two", "stratified"].index(args.sampler)
     for name in args.configs:
         scene_name, w, h, spp, depth, kw = CONFIGS[name]
         spp = max(1, int(round(spp * args.spp_scale)))
+        # stratified: the squarest grid with spp cells
+        skw = dict(sampler=sampler, sampler_arg=max(d for d in range(1, int(spp ** 0.5) + 1) if spp % d == 0)
+                   if args.sampler == "stratified" else 0)
         t0 = time.time()
         sd, camf = scenes.BUILDERS[scene_name](**kw)
         fr = sd.freeze()
@@ -43,12 +48,12 @@ def main():
         info = g.info()
         setup_s = time.time() - t0
         cam = camf(w, h)
-        img, cst = g.render(cam, lib.render_opts(w, h, spp, depth, seed=0, flags=abi.RT_RENDER_COUNTERS))
-        img2, st = g.render(cam, lib.render_opts(w, h, spp, depth, seed=0, flags=abi.RT_RENDER_TIMING))
+        img, cst = g.render(cam, lib.render_opts(w, h, spp, depth, seed=0, flags=abi.RT_RENDER_COUNTERS, **skw))
+        img2, st = g.render(cam, lib.render_opts(w, h, spp, depth, seed=0, flags=abi.RT_RENDER_TIMING, **skw))
         assert img.tobytes() == img2.tobytes()
         alg = cst.segments * 64 + cst.nodes_visited * 32 + sum(
             cst.prims_tested[k] * PRIM_BYTES[k] for k in range(8))
-        out = {"config": name, "scene": scene_name, "width": w, "height": h, "spp": spp, "depth": depth,
+        out = {"config": name, "sampler": args.sampler, "scene": scene_name, "width": w, "height": h, "spp": spp, "depth": depth,
                "prims": info.n_prims, "nodes": info.n_nodes, "tree_depth": info.max_depth,
                "build_ms": round(info.build_ms, 1), "setup_s": round(setup_s, 1),
                "device_MB": round(info.device_bytes / 1e6, 1),
@@ -65,7 +70,7 @@ def main():
             from tests import orc
             o = orc.OracleScene(fr, 4, args.split)
             rng = np.random.default_rng(0)
-            opts = orc.render_opts(w, h, spp, depth, seed=0)
+            opts = orc.render_opts(w, h, spp, depth, seed=0, **skw)
             bad = 0
             for pix in rng.integers(0, w * h, args.check):
                 rgb, _ = o.path_radiance(cam, opts, int(pix) * spp, spp)
