@@ -1082,7 +1082,6 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     if (batch_paths64 >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard too large for one sample per batch");
     const uint32_t batch_paths = (uint32_t)batch_paths64;
     if ((rc = grow_workspace(*db, batch_paths ? batch_paths : 1, o->max_depth)) != RT_OK) return rc;
-    if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) return rc;
 
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
@@ -1093,6 +1092,12 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)o->width * o->height * 4 * sizeof(float), st));
     if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, 32 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ev_begin, st));
+    // the sampler's tables or per-pixel samples belong to the frame's time
+    if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) {
+        (void)hipEventDestroy(ev_begin);
+        (void)hipEventDestroy(ev_end);
+        return rc;
+    }
     uint64_t segments = 0, paths = 0, launches = 0;
     uint32_t batches = 0, max_bounce = 0;
     std::vector<uint32_t> counts(count_words(o->max_depth));

@@ -691,39 +691,61 @@ RT_DEV void sobol_sample(const FrameDev &F, uint32_t px, uint32_t py, uint32_t s
 // uses 1D dimension 0 (time) and 2D dimensions 0 (film) and 1 (lens); the others only advance
 // the generator.
 constexpr int kPixelSamplerDims = 4;
+constexpr uint32_t kPixelSamplesLdsSpp = 256; // 128 KiB of LDS
 
 RT_DEV uint32_t rng_limit(Rng &rng, uint32_t limit) { // uniform_u32_limit, rng.rs:51-59
-    const uint32_t threshold = (~limit + 1u) % limit;
     for (;;) {
         const uint32_t r = rng_u32(rng);
-        if (r >= threshold) return r % limit;
+        // threshold = 2^32 mod limit is below limit: only a draw below limit needs it
+        if (r >= limit || r >= (~limit + 1u) % limit) return r % limit;
     }
 }
-RT_DEV void shuffle1(Rng &rng, float *a, uint32_t n) { // shuffle_dims(.., 1), rng.rs:77-84
+// Where a pixel's samples live while they are made: nowhere (the generator is only advanced),
+// the lane's own stretch of global memory, or the wave's LDS block (element i of lane l at
+// i * 64 + (l ^ (i & 63)): conflict-free when the lanes share i, and for the transposed
+// read-out in which 64 lanes read 64 consecutive i of one lane).
+struct NoArr {
+    RT_DEV float get(uint32_t) const { return 0.0f; }
+    RT_DEV void set(uint32_t, float) const {}
+};
+struct MemArr {
+    float *p;
+    RT_DEV float get(uint32_t i) const { return p[i]; }
+    RT_DEV void set(uint32_t i, float v) const { p[i] = v; }
+};
+struct LdsArr {
+    float *p;
+    uint32_t lane;
+    RT_DEV float get(uint32_t i) const { return p[i * 64u + (lane ^ (i & 63u))]; }
+    RT_DEV void set(uint32_t i, float v) const { p[i * 64u + (lane ^ (i & 63u))] = v; }
+};
+
+template <class A>
+RT_DEV void shuffle1(Rng &rng, const A &a, uint32_t n) { // shuffle_dims(.., 1), rng.rs:77-84
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t other = i + rng_limit(rng, n - i);
-        if (a) {
-            const float t = a[i];
-            a[i] = a[other];
-            a[other] = t;
-        }
+        const float t = a.get(i), o = a.get(other);
+        a.set(i, o);
+        a.set(other, t);
     }
 }
-RT_DEV void shuffle2(Rng &rng, float *a, float *b, uint32_t n) {
+template <class A>
+RT_DEV void shuffle2(Rng &rng, const A &a, const A &b, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t other = i + rng_limit(rng, n - i);
-        const float ta = a[i], tb = b[i];
-        a[i] = a[other];
-        b[i] = b[other];
-        a[other] = ta;
-        b[other] = tb;
+        const float ta = a.get(i), tb = b.get(i), oa = a.get(other), ob = b.get(other);
+        a.set(i, oa);
+        b.set(i, ob);
+        a.set(other, ta);
+        b.set(other, tb);
     }
 }
 // van_der_corput(1, n, ..), zero_two.rs:68-92
-RT_DEV void zero_two_1d(Rng &rng, float *out, uint32_t n) {
+template <class A>
+RT_DEV void zero_two_1d(Rng &rng, const A &out, uint32_t n) {
     uint32_t v = rng_u32(rng);
     for (uint32_t i = 0; i < n; i++) { // sample_gray_code, zero_two.rs:129-136
-        if (out) out[i] = unit_float(v);
+        out.set(i, unit_float(v));
         v ^= 0x80000000u >> __builtin_ctz(i + 1);
     }
     for (uint32_t i = 0; i < n; i++) (void)rng_limit(rng, 1u); // one-element shuffles, zero_two.rs:86-89
@@ -738,11 +760,12 @@ RT_DEV uint32_t sobol2_column(uint32_t c) {
     return v;
 }
 // sobol_2d(1, n, ..), zero_two.rs:95-126
-RT_DEV void zero_two_2d(Rng &rng, float *x, float *y, uint32_t n) {
+template <class A>
+RT_DEV void zero_two_2d(Rng &rng, const A &x, const A &y, uint32_t n) {
     uint32_t vx = rng_u32(rng), vy = rng_u32(rng);
     for (uint32_t i = 0; i < n; i++) { // sample_gray_code2, zero_two.rs:140-155
-        x[i] = unit_float(vx);
-        y[i] = unit_float(vy);
+        x.set(i, unit_float(vx));
+        y.set(i, unit_float(vy));
         const uint32_t c = (uint32_t)__builtin_ctz(i + 1);
         vx ^= 0x80000000u >> c;
         vy ^= sobol2_column(c);
@@ -751,59 +774,120 @@ RT_DEV void zero_two_2d(Rng &rng, float *x, float *y, uint32_t n) {
     shuffle2(rng, x, y, n);
 }
 // stratified_sample_one + shuffle, stratified.rs:35-38,81-88
-RT_DEV void stratified_1d(Rng &rng, float *out, uint32_t n, bool jitter) {
+template <class A>
+RT_DEV void stratified_1d(Rng &rng, const A &out, uint32_t n, bool jitter) {
     const float inv = 1.0f / (float)(int32_t)n;
     for (uint32_t i = 0; i < n; i++) {
         const float delta = jitter ? rng_f(rng) : 0.5f;
-        if (out) out[i] = sel_min(((float)(int32_t)i + delta) * inv, kOneMinusEps);
+        out.set(i, sel_min(((float)(int32_t)i + delta) * inv, kOneMinusEps));
     }
     shuffle1(rng, out, n);
 }
 // stratified_sample_two + shuffle, stratified.rs:40-49,91-116, strata = cells of the nx x ny grid
-RT_DEV void stratified_2d(Rng &rng, float *x, float *y, uint32_t nx, uint32_t ny, bool jitter) {
+template <class A>
+RT_DEV void stratified_2d(Rng &rng, const A &x, const A &y, uint32_t nx, uint32_t ny, bool jitter) {
     const float dx = 1.0f / (float)(int32_t)nx, dy = 1.0f / (float)(int32_t)ny;
     for (uint32_t iy = 0, i = 0; iy < ny; iy++)
         for (uint32_t ix = 0; ix < nx; ix++, i++) {
             const float jx = jitter ? rng_f(rng) : 0.5f;
             const float jy = jitter ? rng_f(rng) : 0.5f;
-            x[i] = sel_min(((float)(int32_t)ix + jx) * dx, kOneMinusEps);
-            y[i] = sel_min(((float)(int32_t)iy + jy) * dy, kOneMinusEps);
+            x.set(i, sel_min(((float)(int32_t)ix + jx) * dx, kOneMinusEps));
+            y.set(i, sel_min(((float)(int32_t)iy + jy) * dy, kOneMinusEps));
         }
     shuffle2(rng, x, y, nx * ny);
 }
 
+// the 1D dimensions (the first is the camera's time, the others only advance the generator)
+template <class A>
+RT_DEV void pixel_samples_1d(const FrameDev &F, Rng &rng, const A &time) {
+    const uint32_t n = F.spp;
+    const bool jitter = !(F.sampler_arg & RT_STRATIFIED_NO_JITTER);
+    if (F.sampler == RT_SAMPLER_ZERO_TWO) {
+        zero_two_1d(rng, time, n);
+        for (int d = 1; d < kPixelSamplerDims; d++) zero_two_1d(rng, NoArr{}, n);
+    } else {
+        stratified_1d(rng, time, n, jitter);
+        for (int d = 1; d < kPixelSamplerDims; d++) stratified_1d(rng, NoArr{}, n, jitter);
+    }
+}
+// one 2D dimension (film, then lens)
+template <class A>
+RT_DEV void pixel_samples_2d(const FrameDev &F, Rng &rng, const A &x, const A &y) {
+    const uint32_t n = F.spp;
+    if (F.sampler == RT_SAMPLER_ZERO_TWO) {
+        zero_two_2d(rng, x, y, n);
+    } else {
+        const uint32_t nx = F.sampler_arg & 0xffffu;
+        stratified_2d(rng, x, y, nx, n / nx, !(F.sampler_arg & RT_STRATIFIED_NO_JITTER));
+    }
+}
+
 RT_DEV bool rank_to_pixel(const FrameDev &F, uint32_t rank, uint32_t &px, uint32_t &py);
 
+RT_DEV bool slot_pixel(const FrameDev &F, uint32_t slot, uint32_t n_slots, int by_rank, uint64_t first_pixel,
+                       uint64_t &pixel) {
+    if (slot >= n_slots) return false;
+    if (by_rank) {
+        uint32_t px, py;
+        if (!rank_to_pixel(F, slot, px, py)) return false;
+        pixel = (uint64_t)py * F.width + px;
+        return true;
+    }
+    pixel = first_pixel + slot;
+    return pixel < (uint64_t)F.width * F.height;
+}
+
+// Any spp: every lane works in place in its own stretch of the sample arrays.
 __global__ __launch_bounds__(kBlock) void k_pixel_samples(FrameDev F, uint32_t n_slots, int by_rank,
                                                           uint64_t first_pixel, float *out) {
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= n_slots) return;
     uint64_t pixel;
-    if (by_rank) {
-        uint32_t px, py;
-        if (!rank_to_pixel(F, slot, px, py)) return;
-        pixel = (uint64_t)py * F.width + px;
-    } else {
-        pixel = first_pixel + slot;
-        if (pixel >= (uint64_t)F.width * F.height) return;
-    }
+    if (!slot_pixel(F, slot, n_slots, by_rank, first_pixel, pixel)) return;
     Rng rng;
     rng_seq(rng, (1ull << 63) | ((F.seed << 32) + pixel));
-    const uint32_t n = F.spp;
-    float *base = out + (size_t)slot * n;
-    float *fx = base, *fy = base + F.sample_stride, *time = base + 2 * (size_t)F.sample_stride;
-    float *lu = base + 3 * (size_t)F.sample_stride, *lv = base + 4 * (size_t)F.sample_stride;
-    if (F.sampler == RT_SAMPLER_ZERO_TWO) {
-        for (int d = 0; d < kPixelSamplerDims; d++) zero_two_1d(rng, d == 0 ? time : nullptr, n);
-        zero_two_2d(rng, fx, fy, n);
-        zero_two_2d(rng, lu, lv, n);
-    } else {
-        const uint32_t nx = F.sampler_arg & 0xffffu, ny = n / nx;
-        const bool jitter = !(F.sampler_arg & RT_STRATIFIED_NO_JITTER);
-        for (int d = 0; d < kPixelSamplerDims; d++) stratified_1d(rng, d == 0 ? time : nullptr, n, jitter);
-        stratified_2d(rng, fx, fy, nx, ny, jitter);
-        stratified_2d(rng, lu, lv, nx, ny, jitter);
-    }
+    float *base = out + (size_t)slot * F.spp;
+    const size_t st = F.sample_stride;
+    pixel_samples_1d(F, rng, MemArr{base + 2 * st});
+    pixel_samples_2d(F, rng, MemArr{base}, MemArr{base + st});
+    pixel_samples_2d(F, rng, MemArr{base + 3 * st}, MemArr{base + 4 * st});
+}
+
+// spp <= kPixelSamplesLdsSpp: one wave per workgroup works in LDS (2 * spp * 64 floats) and
+// copies each finished dimension out with the lanes running along a pixel's samples, so the
+// stores are contiguous.
+__global__ __launch_bounds__(64) void k_pixel_samples_lds(FrameDev F, uint32_t n_slots, int by_rank,
+                                                          uint64_t first_pixel, float *out) {
+    extern __shared__ float lds_samples[];
+    const uint32_t lane = threadIdx.x, slot0 = blockIdx.x * 64u, n = F.spp;
+    uint64_t pixel = 0;
+    const bool valid = slot_pixel(F, slot0 + lane, n_slots, by_rank, first_pixel, pixel);
+    const uint64_t valid_mask = __ballot(valid);
+    Rng rng;
+    rng_seq(rng, (1ull << 63) | ((F.seed << 32) + pixel));
+    const LdsArr a{lds_samples, lane}, b{lds_samples + (size_t)n * 64u, lane};
+    // element e of the wave's 64 * n floats of one array belongs to pixel e / n, sample e % n
+    auto copy_out = [&](const float *lds, uint32_t k) {
+        __syncthreads();
+        float *g = out + (size_t)k * F.sample_stride + (size_t)slot0 * n;
+        uint32_t p = lane / n, i = lane - p * n;
+        for (uint32_t e = lane; e < 64u * n; e += 64u) {
+            if ((valid_mask >> p) & 1ull) g[e] = lds[i * 64u + (p ^ (i & 63u))];
+            i += 64u;
+            while (i >= n) {
+                i -= n;
+                p++;
+            }
+        }
+        __syncthreads();
+    };
+    if (valid) pixel_samples_1d(F, rng, a);
+    copy_out(a.p, 2);
+    if (valid) pixel_samples_2d(F, rng, a, b);
+    copy_out(a.p, 0);
+    copy_out(b.p, 1);
+    if (valid) pixel_samples_2d(F, rng, a, b);
+    copy_out(a.p, 3);
+    copy_out(b.p, 4);
 }
 
 // Camera sample of path (pixel, s): film offsets u[0], u[1], time u[2], lens u[3], u[4].
@@ -1438,8 +1522,16 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
 hipError_t launch_pixel_samples(const FrameDev &F, uint32_t n_slots, bool by_rank, uint64_t first_pixel, float *out,
                                 hipStream_t stream) {
     if (!n_slots) return hipSuccess;
-    hipLaunchKernelGGL(k_pixel_samples, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, n_slots,
-                       by_rank ? 1 : 0, first_pixel, out);
+    if (F.spp <= kPixelSamplesLdsSpp) {
+        const size_t lds = (size_t)F.spp * 2 * 64 * sizeof(float);
+        hipError_t e = allow_lds(k_pixel_samples_lds, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pixel_samples_lds, dim3((n_slots + 63) / 64), dim3(64), lds, stream, F, n_slots,
+                           by_rank ? 1 : 0, first_pixel, out);
+    } else {
+        hipLaunchKernelGGL(k_pixel_samples, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F,
+                           n_slots, by_rank ? 1 : 0, first_pixel, out);
+    }
     return hipGetLastError();
 }
 

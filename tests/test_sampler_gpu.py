@@ -109,3 +109,22 @@ def test_sobol_at_frame_size(scene_cache):
         a = lib.generate_rays(cam(w, h), lib.render_opts(w, h, spp, 6, seed=3, **kw), first, 4096)
         b = orc.generate_rays(cam(w, h), orc.render_opts(w, h, spp, 6, seed=3, **kw), first, 4096)
         assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp,kw", [(512, dict(sampler=abi.RT_SAMPLER_ZERO_TWO)),
+                                    (288, dict(sampler=abi.RT_SAMPLER_STRATIFIED, sampler_arg=16)),
+                                    (256, dict(sampler=abi.RT_SAMPLER_ZERO_TWO)),
+                                    (1, dict(sampler=abi.RT_SAMPLER_ZERO_TWO)),
+                                    (7, dict(sampler=abi.RT_SAMPLER_STRATIFIED, sampler_arg=7))])
+def test_pixel_samplers_at_small_and_large_spp(spp, kw, scene_cache):
+    """Above 256 spp the per-pixel samples are made in global memory, up to it in LDS."""
+    _, cam, fr = scene_cache("random")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h = 9, 5
+    a = lib.generate_rays(cam(w, h), lib.render_opts(w, h, spp, 4, seed=4, **kw), spp + 3, w * h * spp - spp - 3)
+    b = orc.generate_rays(cam(w, h), orc.render_opts(w, h, spp, 4, seed=4, **kw), spp + 3, w * h * spp - spp - 3)
+    assert a.tobytes() == b.tobytes()
+    img, _ = g.render(cam(w, h), lib.render_opts(w, h, spp, 4, seed=4, **kw))
+    ref, _ = o.render(cam(w, h), orc.render_opts(w, h, spp, 4, seed=4, **kw))
+    assert img.tobytes() == ref.tobytes()
