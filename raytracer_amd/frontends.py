@@ -337,9 +337,16 @@ def load_pbrt(text):
                 camera["c2w"] = np.linalg.inv(ctm)
                 camera["fov"] = float(p.get("fov", ("float", [90.0]))[1][0])
                 ctm = identity()
-            elif d == "Sampler":
-                settings["spp"] = int(p.get("pixelsamples", ("integer", [16]))[1][0])
+            elif d == "Sampler":  # parsers/src/pbrt/mod.rs:486-520,688-696
                 settings["sampler"] = kind
+                if kind == "stratified":
+                    settings["strata"] = (int(p.get("xsamples", ("integer", [4]))[1][0]),
+                                          int(p.get("ysamples", ("integer", [4]))[1][0]))
+                    jitter = p.get("jitter", ("bool", [True]))[1][0]
+                    settings["jitter"] = jitter in (True, "true", '"true"')
+                    settings["spp"] = settings["strata"][0] * settings["strata"][1]
+                else:
+                    settings["spp"] = int(p.get("pixelsamples", ("integer", [16]))[1][0])
             elif d == "Film":
                 settings["width"] = int(p.get("xresolution", ("integer", [640]))[1][0])
                 settings["height"] = int(p.get("yresolution", ("integer", [480]))[1][0])
@@ -385,6 +392,26 @@ def load_pbrt(text):
         return perspective_camera(width, height, fov, c2w)
 
     return s, cam, settings
+
+
+def sampler_options(settings):
+    """Keyword arguments for lib.render_opts (spp, sampler, sampler_arg) from a loaded file's
+    Sampler directive (names as parsers/src/pbrt/mod.rs:688-696)."""
+    kind = settings.get("sampler", "random")
+    spp = int(settings.get("spp", 16))
+    if kind == "halton":
+        return dict(spp=spp, sampler=abi.RT_SAMPLER_HALTON)
+    if kind == "sobol":
+        return dict(spp=spp, sampler=abi.RT_SAMPLER_SOBOL)
+    if kind in ("02sequence", "lowdiscrepancy"):
+        return dict(spp=1 << max(0, spp - 1).bit_length(), sampler=abi.RT_SAMPLER_ZERO_TWO)  # round_up_pow_2
+    if kind == "stratified":
+        nx, ny = settings.get("strata", (4, 4))
+        return dict(spp=nx * ny, sampler=abi.RT_SAMPLER_STRATIFIED,
+                    sampler_arg=nx | (0 if settings.get("jitter", True) else abi.RT_STRATIFIED_NO_JITTER))
+    if kind == "random":
+        return dict(spp=spp, sampler=abi.RT_SAMPLER_RANDOM)
+    raise SceneError("sampler %r is not supported" % kind)
 
 
 def load(path):

@@ -100,3 +100,26 @@ def test_errors_name_the_problem():
         frontends.load_toml('[[world]]\nshape = "Sphere"\ncentre=[0,0,0]\nradius=1\nmaterial="nope"\n')
     with pytest.raises(frontends.SceneError, match="not supported"):
         frontends.load_pbrt('WorldBegin\nShape "cone"\nWorldEnd\n')
+
+
+def test_pbrt_sampler_directives():
+    """Sampler names of parsers/src/pbrt/mod.rs:688-696 -> render options."""
+    from raytracer_amd import abi
+    base = 'Camera "perspective" "float fov" 45\n%s\nWorldBegin\nShape "sphere" "float radius" 1\nWorldEnd\n'
+    cases = [
+        ('Sampler "halton" "integer pixelsamples" 128', dict(spp=128, sampler=abi.RT_SAMPLER_HALTON)),
+        ('Sampler "sobol" "integer pixelsamples" 48', dict(spp=48, sampler=abi.RT_SAMPLER_SOBOL)),
+        ('Sampler "02sequence" "integer pixelsamples" 48', dict(spp=64, sampler=abi.RT_SAMPLER_ZERO_TWO)),
+        ('Sampler "lowdiscrepancy" "integer pixelsamples" 64', dict(spp=64, sampler=abi.RT_SAMPLER_ZERO_TWO)),
+        ('Sampler "stratified" "integer xsamples" 8 "integer ysamples" 4',
+         dict(spp=32, sampler=abi.RT_SAMPLER_STRATIFIED, sampler_arg=8)),
+        ('Sampler "stratified" "bool jitter" "false" "integer xsamples" [2] "integer ysamples" [3]',
+         dict(spp=6, sampler=abi.RT_SAMPLER_STRATIFIED, sampler_arg=2 | abi.RT_STRATIFIED_NO_JITTER)),
+        ('Sampler "random" "integer pixelsamples" 5', dict(spp=5, sampler=abi.RT_SAMPLER_RANDOM)),
+    ]
+    for text, want in cases:
+        _, _, st = frontends.load_pbrt(base % text)
+        assert frontends.sampler_options(st) == want
+    _, _, st = frontends.load_pbrt(base % 'Sampler "maxmindist" "integer pixelsamples" 16')
+    with pytest.raises(frontends.SceneError):
+        frontends.sampler_options(st)
