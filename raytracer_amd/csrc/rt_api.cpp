@@ -479,7 +479,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     // memory.  If the records and at least kMinLds stack levels of a 1024-thread workgroup
     // fit in one CU's LDS the tree is traversed from LDS (one workgroup per CU, 16-bit
     // references); otherwise 256-thread workgroups read records from global memory, with
-    // as many stack levels in LDS as still leave room for four workgroups per CU.
+    // as many stack levels in LDS as still leave room for kGlobalWaves workgroups per CU.
     const uint32_t slots = s.tree.max_depth > 1 ? s.tree.max_depth - 1 : 1;
     const size_t lds_cu = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlockOptin);
     constexpr uint32_t kMinLds = 8;
@@ -492,7 +492,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         lds_nodes = stack_lds >= std::min(slots, kMinLds);
     }
     if (force && !strcmp(force, "global")) lds_nodes = false;
-    if (!lds_nodes) stack_lds = (uint32_t)std::min<size_t>(slots, lds_cu / 4 / (256 * 8));
+    if (!lds_nodes) stack_lds = (uint32_t)std::min<size_t>(slots, (lds_cu / rt::kGlobalWaves - 512) / (256 * 8));
     // test hook: fewer LDS levels, so that the private part of the stack is exercised
     if (const char *cap = getenv("RT355_STACK_LDS")) {
         const uint32_t v = (uint32_t)atoi(cap);
@@ -507,10 +507,11 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     if (lds_nodes) {
         db.shape.grid = std::max(2u, (uint32_t)prop.multiProcessorCount / 2 * 2);
     } else {
-        size_t lds = rt::lds_bytes(false, n_pairs, stack_lds);
-        uint32_t per_cu = (uint32_t)(lds_cu / (lds ? lds : 1));
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
+        // as many persistent workgroups as are resident at once: one more per CU would only
+        // start when another ends, and its rays would be the frame's tail
+        uint32_t per_cu = 1;
+        HIP_TRY(rt::resident_workgroups(rt::lds_bytes(false, n_pairs, stack_lds), &per_cu));
+        if (per_cu > rt::kGlobalWaves) per_cu = rt::kGlobalWaves;
         db.shape.grid = std::max(8u, (uint32_t)prop.multiProcessorCount * per_cu / 8 * 8);
     }
     static_assert(rt::kShards == 32, "grid rounding above assumes 32 sub-queues");

@@ -22,18 +22,11 @@
 namespace rt {
 
 constexpr int kBlock = 256;
-// minimum resident waves per SIMD the register allocator must leave room for
-#ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 4
-#endif
 // lanes holding a leaf that trigger a leaf round (64 = wait for every lane)
 #ifndef RT_LEAF_LANES
 #define RT_LEAF_LANES 32
 #endif
 constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
-#ifndef RT_BOUNCE_WAVES
-#define RT_BOUNCE_WAVES 4
-#endif
 constexpr uint32_t kDead = 0xFFFFFFFFu;
 
 RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
@@ -57,7 +50,7 @@ struct Shape;
 template <>
 struct Shape<false> {
     static constexpr int kThreads = kBlock;
-    static constexpr int kWaves = RT_TRACE_WAVES;
+    static constexpr int kWaves = (int)kGlobalWaves;
     using RefT = uint32_t;
 };
 template <>
@@ -1358,7 +1351,7 @@ struct BounceFeed {
 // that is a multiple of kShards, so that wave w reads and writes sub-queue
 // w % kShards only.
 template <bool COUNT, bool LDSN>
-__global__ __launch_bounds__(Shape<LDSN>::kThreads, LDSN ? 4 : RT_BOUNCE_WAVES) void k_bounce(
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_bounce(
     SceneDev S, Queue qin, Queue qout, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
     float4 *radiance, uint8_t *scratch, unsigned long long *counters) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1548,6 +1541,23 @@ hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue 
     hipLaunchKernelGGL(k_generate, dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, cam, q,
                        counts, n_local, s0, s_count);
     return hipGetLastError();
+}
+
+hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu) {
+    int n[4] = {0, 0, 0, 0};
+    hipError_t e = allow_lds(k_bounce<false, false>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_bounce<true, false>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_intersect<false, false>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_occluded<false>, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], k_bounce<false, false>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], k_bounce<true, false>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], k_intersect<false, false>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], k_occluded<false>, kBlock, lds_bytes);
+    if (e != hipSuccess) return e;
+    int m = n[0];
+    for (int k = 1; k < 4; k++) m = n[k] < m ? n[k] : m;
+    *per_cu = m > 0 ? (uint32_t)m : 1u;
+    return hipSuccess;
 }
 
 uint32_t bounce_waves(const LaunchShape &L) { return L.grid * ((L.lds_nodes ? 1024u : (uint32_t)kBlock) / 64u); }

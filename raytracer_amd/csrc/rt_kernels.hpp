@@ -80,6 +80,13 @@ struct LaunchShape {
     bool lds_nodes;  // node array staged in LDS (1024-thread workgroups), else 256-thread workgroups
 };
 
+// Resident 256-thread workgroups per CU (= waves per SIMD) the kernels that read the tree
+// from global memory are compiled for: more of them hide more memory latency, each gets
+// fewer registers and a smaller share of the CU's LDS for its stacks.
+#ifndef RT_GLOBAL_WAVES
+#define RT_GLOBAL_WAVES 6
+#endif
+constexpr uint32_t kGlobalWaves = RT_GLOBAL_WAVES;
 // Stack entries a lane can keep in a private array beyond its LDS levels.
 constexpr uint32_t kSpillLevels = 56;
 // Dynamic LDS of a trace workgroup (interior records for the LDS-resident shape + stacks).
@@ -100,6 +107,9 @@ hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue 
 constexpr uint32_t kParkSlots = 128;
 constexpr uint32_t kSaveWords = 20;
 constexpr size_t kWaveScratchBytes = 2 * kParkSlots * 24 + kSaveWords * 64 * 4;
+// Workgroups of the global-memory trace kernels that fit on one CU together with this much
+// dynamic LDS each (the smallest answer over the kernels, from the runtime's occupancy query).
+hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu);
 // waves of the bounce grid (scratch must hold kWaveScratchBytes for each)
 uint32_t bounce_waves(const LaunchShape &L);
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
