@@ -260,6 +260,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             const uint32_t level = sp < levels ? sp : levels - 1;
             uint32_t e = s_ref[level * kStride];
             float t = s_near[level * kStride];
+            asm volatile("" : "+v"(e), "+v"(t)); // keeps both LDS reads DS instructions (see above)
             if constexpr (LDSN) e = (e & 0x7fffu) | ((e & 0x8000u) << 16);
             if (sp >= levels) {
                 e = spill_ref[sp - levels];
