@@ -425,6 +425,10 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
             }
             media.push_back(o);
             lp.index = (uint32_t)media.size() - 1;
+            if (m.boundary_kind == RT_BOUNDARY_SPHERE) {
+                lp.kind |= rt::kMediumInSphere;
+                memcpy(&lp.index, &o.neg_inv_density, sizeof(float));
+            }
             break;
         }
         }

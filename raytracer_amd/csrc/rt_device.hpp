@@ -17,7 +17,7 @@ namespace rt {
 // ---- resident scene (device pointers), passed to kernels by value --------------
 struct LeafPrim {      // one entry per primitive, in leaf order (BVH::primitives, bvh.rs:35)
     uint32_t kind;     // rt_prim_kind | reverse << 8 | kLastInLeaf | kRareShade | xform << 16
-    uint32_t index;    // index into the typed table (tables are packed in leaf order)
+    uint32_t index;    // index into the typed table (tables are packed in leaf order); see kMediumInSphere
     uint32_t prim;     // caller's primitive index
     uint32_t material;
     float4 geom;       // sphere: {c.xyz, r}; medium in a sphere: its boundary {c.xyz, r}; else unused
@@ -28,6 +28,9 @@ constexpr uint32_t kLastInLeaf = 0x200u; // LeafPrim.kind: no further primitive 
 // triangle, rectangle or box without instance transform, carrying a Lambertian, metallic
 // or emissive material whose texture is a solid colour or a 3-D checker of solid colours)
 constexpr uint32_t kRareShade = 0x400u;
+// LeafPrim.kind of a medium bounded by a sphere: geom is the sphere and index holds the bits
+// of -1 / density instead of a row of SceneDev::media
+constexpr uint32_t kMediumInSphere = 0x800u;
 constexpr uint32_t kLeafRef = 0x80000000u; // child reference: leaf starting at primitive (ref & ~kLeafRef)
 
 struct GSphere { // derived form of rt_gsphere, 128 B
@@ -354,6 +357,17 @@ RT_DEV bool box_interval_rd(v3 o, v3 d, v3 rd, const rt_box &b, float &tn_o, flo
     return true;
 }
 
+// rt_box as two 16-byte loads (the per-axis reads of the interval tests would otherwise
+// become six conditional 4-byte loads)
+RT_DEV rt_box load_box(const rt_box *boxes, uint32_t i) {
+    const float4 *p = reinterpret_cast<const float4 *>(boxes + i);
+    const float4 a = p[0], b = p[1];
+    rt_box r;
+    r.lo[0] = a.x; r.lo[1] = a.y; r.lo[2] = a.z; r._p0 = 0.0f;
+    r.hi[0] = b.x; r.hi[1] = b.y; r.hi[2] = b.z; r._p1 = 0.0f;
+    return r;
+}
+
 RT_DEV void rect_axes(uint32_t axis, int &A, int &B) {
     if (axis == 0) { A = 1; B = 2; }
     else if (axis == 1) { A = 0; B = 2; }
@@ -480,28 +494,31 @@ RT_DEV float medium_uniform(const Ray &ray, uint32_t prim) {
     h = hash32(prim ^ h);
     return (float)(h >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
-RT_DEV bool medium_test(const SceneDev &S, uint32_t prim, const Medium &m, float4 sp, const Ray &ray, v3 rd,
-                        float &t_out) {
-    float t_in, t_out_b;
-    v3 o, d;
-    if (m.boundary_kind == RT_BOUNDARY_SPHERE) {
-        o = ray.o - mk(sp.x, sp.y, sp.z);
-        d = ray.d;
-        if (!sphere_roots(o, d, sp.w, t_in, t_out_b)) return false;
-    } else if (m.xform == 0) {
-        int fn, ff;
-        if (!box_interval_rd(ray.o, ray.d, rd, S.boxes[m.boundary_index], t_in, t_out_b, fn, ff)) return false;
+RT_DEV bool medium_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, v3 rd, float &t_out) {
+    float t_in, t_out_b, neg_inv_density;
+    if (lp.kind & kMediumInSphere) { // everything the test needs is in the leaf entry
+        const float4 sp = lp.geom;
+        neg_inv_density = __uint_as_float(lp.index);
+        if (!sphere_roots(ray.o - mk(sp.x, sp.y, sp.z), ray.d, sp.w, t_in, t_out_b)) return false;
     } else {
+        const Medium m = S.media[lp.index];
+        neg_inv_density = m.neg_inv_density;
         int fn, ff;
-        to_object(S, m.xform, ray, o, d);
-        if (!box_interval(o, d, S.boxes[m.boundary_index], t_in, t_out_b, fn, ff)) return false;
+        if (m.xform == 0) {
+            if (!box_interval_rd(ray.o, ray.d, rd, load_box(S.boxes, m.boundary_index), t_in, t_out_b, fn, ff))
+                return false;
+        } else {
+            v3 o, d;
+            to_object(S, m.xform, ray, o, d);
+            if (!box_interval(o, d, load_box(S.boxes, m.boundary_index), t_in, t_out_b, fn, ff)) return false;
+        }
     }
     if (t_in < 0.0f) t_in = 0.0f;
     if (t_out_b > ray.t_max) t_out_b = ray.t_max;
     if (!(t_in < t_out_b)) return false;
     float len = length(ray.d);
     float inside = (t_out_b - t_in) * len;
-    float hit_dist = m.neg_inv_density * p_log(medium_uniform(ray, prim));
+    float hit_dist = neg_inv_density * p_log(medium_uniform(ray, lp.prim));
     if (hit_dist > inside) return false;
     float t = t_in + hit_dist / len;
     if (!(t > 0.0f && t <= ray.t_max)) return false;
@@ -551,10 +568,10 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, v3 
         v3 o, d;
         int fn, ff;
         if ((lp.kind >> 16) == 0) {
-            if (!box_interval_rd(ray.o, ray.d, rd, S.boxes[lp.index], t0, t1, fn, ff)) return false;
+            if (!box_interval_rd(ray.o, ray.d, rd, load_box(S.boxes, lp.index), t0, t1, fn, ff)) return false;
         } else {
             to_object(S, lp.kind >> 16, ray, o, d);
-            if (!box_interval(o, d, S.boxes[lp.index], t0, t1, fn, ff)) return false;
+            if (!box_interval(o, d, load_box(S.boxes, lp.index), t0, t1, fn, ff)) return false;
         }
         float tt = t0;
         int face = fn;
@@ -565,7 +582,7 @@ RT_DEV bool prim_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, v3 
         return true;
     }
     case RT_GSPHERE: return gsphere_test(S.gsph[lp.index], ray, t);
-    case RT_MEDIUM: return medium_test(S, lp.prim, S.media[lp.index], lp.geom, ray, rd, t);
+    case RT_MEDIUM: return medium_test(S, lp, ray, rd, t);
     default: return false;
     }
 }
