@@ -400,7 +400,14 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                         asm volatile("" ::"v"(sink));
                     }
 #endif
-                    const bool hit = prim_test(S, lp, L.ray, inv, t, b0, b1, b2);
+                    // One component of the direction goes through an opaque copy inside the loop:
+                    // otherwise everything a kind derives from the ray alone (the triangle's
+                    // permutation and shear with three divisions, most of the medium's hash, the
+                    // direction's length) is hoisted in front of the loop and runs in every leaf
+                    // round, for every lane, whether or not a primitive of that kind turns up.
+                    Ray pr = L.ray;
+                    pr.d.z = opaque(pr.d.z);
+                    const bool hit = prim_test(S, lp, pr, inv, t, b0, b1, b2);
                     if (hit) {
                         L.ray.t_max = t;
                         L.best = i | ((lp.kind & kRareShade) ? kBestRare : 0u);
