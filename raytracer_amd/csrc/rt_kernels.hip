@@ -129,7 +129,7 @@ struct Counters {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 // finished or empty lanes that trigger a refill while unread rays remain
 #ifndef RT_REFILL_LANES
-#define RT_REFILL_LANES 32
+#define RT_REFILL_LANES 24
 #endif
 constexpr uint32_t kRefillLanes = RT_REFILL_LANES;
 #ifndef RT_PRIMARY_REFILL_LANES
