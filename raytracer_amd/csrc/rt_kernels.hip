@@ -132,10 +132,28 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 #define RT_REFILL_LANES 24
 #endif
 constexpr uint32_t kRefillLanes = RT_REFILL_LANES;
+// the same for the kernels that read the tree from global memory: their waves wait on memory
+// rather than on the ALUs, so an idle lane costs more and a refill turn less
+#ifndef RT_REFILL_LANES_GLOBAL
+#define RT_REFILL_LANES_GLOBAL 24
+#endif
+#ifndef RT_REFILL_LANES_GLOBAL_HIT
+#define RT_REFILL_LANES_GLOBAL_HIT 12 // closest-hit queries without shading: a refill turn is cheap
+#endif
+template <bool LDSN>
+constexpr uint32_t refill_lanes_of() { return LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL; }
 #ifndef RT_PRIMARY_REFILL_LANES
 #define RT_PRIMARY_REFILL_LANES 65
 #endif
 constexpr uint32_t kPrimaryRefillLanes = RT_PRIMARY_REFILL_LANES;
+#ifndef RT_PRIMARY_REFILL_LANES_GLOBAL
+#define RT_PRIMARY_REFILL_LANES_GLOBAL 16
+#endif
+#ifndef RT_BOUNCE_REFILL_LANES_GLOBAL
+#define RT_BOUNCE_REFILL_LANES_GLOBAL 32 // a refill turn of the bounce kernel also parks and shades
+#endif
+template <bool LDSN>
+constexpr uint32_t primary_refill_lanes_of() { return LDSN ? kPrimaryRefillLanes : (uint32_t)RT_PRIMARY_REFILL_LANES_GLOBAL; }
 
 constexpr uint32_t kBestRare = 0x80000000u;
 
@@ -216,7 +234,7 @@ struct Blocks {
 // void finish(), called once when every ray of the wave has been consumed.
 template <bool ANY, bool COUNT, bool LDSN, class Feed>
 RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt,
-                         const uint32_t refill_lanes = kRefillLanes) {
+                         const uint32_t refill_lanes = refill_lanes_of<LDSN>()) {
     constexpr int kStride = Shape<LDSN>::kThreads;
     using RefT = typename Shape<LDSN>::RefT;
     RefT *const s_ref = tv.ref;
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
     HitFeed feed{S, rays, hits, Blocks{wave_index() * 64, 0u, n, wave_total() * 64}, kNone};
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt);
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL_HIT);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -1382,7 +1400,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u};
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? kPrimaryRefillLanes : kRefillLanes);
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
     if (COUNT) flush_counters(cnt, counters);
 }
 
