@@ -27,6 +27,9 @@ constexpr int kBlock = 256;
 #define RT_LEAF_LANES 32
 #endif
 constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
+#ifndef RT_LEAF_LANES_GLOBAL
+#define RT_LEAF_LANES_GLOBAL 32
+#endif
 constexpr uint32_t kDead = 0xFFFFFFFFu;
 
 RT_DEV uint32_t lane_rank(uint64_t mask) { // set bits of mask below this lane
@@ -236,6 +239,7 @@ template <bool ANY, bool COUNT, bool LDSN, class Feed>
 RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt,
                          const uint32_t refill_lanes = refill_lanes_of<LDSN>()) {
     constexpr int kStride = Shape<LDSN>::kThreads;
+    constexpr uint32_t leaf_lanes = LDSN ? kLeafLanes : (uint32_t)RT_LEAF_LANES_GLOBAL;
     using RefT = typename Shape<LDSN>::RefT;
     RefT *const s_ref = tv.ref;
     float *const s_near = tv.near;
@@ -336,7 +340,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             if (m_step == 0) break;
             const uint32_t n_step = (uint32_t)__popcll(m_step);
             const uint32_t n_hold = (uint32_t)__popcll(__ballot(!stepping && cur != kNone));
-            if (n_hold >= kLeafLanes) break;
+            if (n_hold >= leaf_lanes) break;
             if (can_refill && 64u - n_step - n_hold >= refill_lanes) break;
             PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
             if (stepping) {
@@ -395,7 +399,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
         // leaf round, bvh.rs:763-776: when enough lanes hold a leaf or nobody can step
         const bool holding = (cur >> 31) != 0 && cur != kNone;
         const uint32_t n_hold = (uint32_t)__popcll(__ballot(holding));
-        if (n_hold >= kLeafLanes || (n_hold != 0 && __ballot((cur >> 31) == 0) == 0)) {
+        if (n_hold >= leaf_lanes || (n_hold != 0 && __ballot((cur >> 31) == 0) == 0)) {
             PROF(uint32_t my_iters = 0;)
             if (holding) {
                 bool stop = false;
