@@ -125,7 +125,8 @@ struct Counters {
     uint32_t prims[8];
     // 0 interior steps, 1 lanes stepping in them, 2 leaf rounds, 3 primitive iterations of
     // leaf rounds (longest lane), 4 lanes x primitives tested, 5 cycles in interior steps,
-    // 6 cycles in leaf rounds, 8 cycles in feed turns, 9 cycles in all, 10 feed turns, 11 rays
+    // 6 cycles in leaf rounds, 7 cycles in shading batches (part of 8), 8 cycles in feed turns,
+    // 9 cycles in all, 10 feed turns, 11 rays
     PROF(unsigned long long p[12];)
 };
 
@@ -1212,6 +1213,7 @@ struct BounceFeed {
     uint32_t *save;     // kSaveWords x 64, word k of lane l at save[k * 64 + l]
     uint32_t parked[2]; // wave uniform
     uint32_t entry;     // queue entry of the ray this lane is tracing
+    PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     RT_DEV bool more() const { return blocks.more(); }
 
     RT_DEV void compact(bool alive, const Lane &P, uint32_t local, v3 beta, const Rng &rng, uint32_t gpath) {
@@ -1286,6 +1288,7 @@ struct BounceFeed {
         }
         parked[0] += (uint32_t)__popcll(m0);
         parked[1] += (uint32_t)__popcll(m1);
+        PROF(const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();)
         if (parked[0] >= 64 || parked[1] >= 64) {
             // The traversing lanes' state leaves the registers while a batch is shaded.  When no
             // lane is traversing (small scenes: the rays of a wave finish together) there is
@@ -1338,6 +1341,7 @@ struct BounceFeed {
                 entry = 0;
             }
         }
+        PROF(prof_shade += __builtin_amdgcn_s_memtime() - prof_t0;)
         // next rays
         const uint32_t next = blocks.take(free);
         bool fresh = false;
@@ -1405,6 +1409,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
+    PROF(cnt.p[7] = feed.prof_shade;)
     if (COUNT) flush_counters(cnt, counters);
 }
 
