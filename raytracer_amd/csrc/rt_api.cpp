@@ -257,6 +257,19 @@ void release(DeviceBuffers &db) {
     db.sampler_bytes = 0;
 }
 
+// HIP events of one call; `timed` lists the pairs recorded around the bounce launches.
+struct EventList {
+    std::vector<hipEvent_t> all, timed;
+    hipError_t make(hipEvent_t *e) {
+        hipError_t rc = hipEventCreate(e);
+        if (rc == hipSuccess) all.push_back(*e);
+        return rc;
+    }
+    ~EventList() {
+        for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    }
+};
+
 // 0, or the reason the sampler options are not accepted (Stratified::new / ZeroTwo::new arguments)
 const char *sampler_problem(const rt_render_opts &o) {
     if (o.sampler > RT_SAMPLER_STRATIFIED) return "unknown sampler";
@@ -1090,19 +1103,16 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
 
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
-    std::vector<hipEvent_t> ev;
+    EventList events; // destroyed on every way out
+    std::vector<hipEvent_t> &ev = events.timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    HIP_TRY(hipEventCreate(&ev_begin));
-    HIP_TRY(hipEventCreate(&ev_end));
+    HIP_TRY(events.make(&ev_begin));
+    HIP_TRY(events.make(&ev_end));
     HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)o->width * o->height * 4 * sizeof(float), st));
     if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, 32 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ev_begin, st));
     // the sampler's tables or per-pixel samples belong to the frame's time
-    if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) {
-        (void)hipEventDestroy(ev_begin);
-        (void)hipEventDestroy(ev_end);
-        return rc;
-    }
+    if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) return rc;
     uint64_t segments = 0, paths = 0, launches = 0;
     uint32_t batches = 0, max_bounce = 0;
     std::vector<uint32_t> counts(count_words(o->max_depth));
@@ -1116,8 +1126,8 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         for (uint32_t b = 0; b < o->max_depth; b++) {
             if (want_timing) {
                 hipEvent_t e0, e1;
-                HIP_TRY(hipEventCreate(&e0));
-                HIP_TRY(hipEventCreate(&e1));
+                HIP_TRY(events.make(&e0));
+                HIP_TRY(events.make(&e1));
                 HIP_TRY(hipEventRecord(e0, st));
                 ev.push_back(e0);
                 ev.push_back(e1);
@@ -1182,9 +1192,6 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
 #endif
         }
     }
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ev_begin);
-    (void)hipEventDestroy(ev_end);
     return RT_OK;
 }
 

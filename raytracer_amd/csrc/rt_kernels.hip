@@ -1138,6 +1138,15 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     // (Lambertian, metallic, isotropic).  Per path the RNG draws stay in
     // the same order as when each material is evaluated on its own.
     v3 tex = mk(1.0f, 1.0f, 1.0f), rs = mk(0.0f, 0.0f, 0.0f);
+#ifdef RT_DOUBLE_RS
+    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC) {
+        Rng r2 = rng;
+        r2.inc = (uint64_t)__float_as_uint(opaque(__uint_as_float((uint32_t)r2.inc))) | (r2.inc & 0xffffffff00000000ull);
+        v3 q = random_in_unit_sphere(r2);
+        float sink = q.x + q.y + q.z;
+        asm volatile("" ::"v"(sink));
+    }
+#endif
     if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
         rs = random_in_unit_sphere(rng);
     if (PLAIN) tex = texture_plain(S, m.texture, h.p);
