@@ -1423,20 +1423,41 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 }
 
 // Adds the batch's samples to the running per-pixel sums in sample order; the
-// last batch divides by spp.  One thread per owned pixel.
+// last batch divides by spp.  One thread per owned pixel.  A pixel's samples are
+// consecutive in memory, so a wave's 64 pixels are 64 rows of s_count entries: the wave
+// reads them eight columns at a time with its lanes running along the rows (8 rows x 128
+// contiguous bytes per load), passes them through LDS, and every lane then adds its own
+// row's eight values in order.
+constexpr uint32_t kResolveCols = 8;
 __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev F, const float4 *radiance, uint32_t n_ranks,
                                                     uint32_t s_count, int finish, float4 *rgba) {
-    uint32_t rank = blockIdx.x * kBlock + threadIdx.x, px, py;
-    if (rank >= n_ranks || !rank_to_pixel(F, rank, px, py)) return;
-    size_t pix = (size_t)py * F.width + px;
-    float4 acc = rgba[pix];
-    const float4 *r = radiance + (size_t)rank * s_count;
-    for (uint32_t s = 0; s < s_count; s++) {
-        float4 v = r[s];
-        acc.x += v.x;
-        acc.y += v.y;
-        acc.z += v.z;
+    __shared__ float4 tile[kBlock / 64][64][kResolveCols + 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t rank0 = blockIdx.x * kBlock + wave * 64u, rank = rank0 + lane;
+    uint32_t px = 0, py = 0;
+    const bool owned = rank < n_ranks && rank_to_pixel(F, rank, px, py);
+    const size_t pix = (size_t)py * F.width + px;
+    float4 acc = owned ? rgba[pix] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t col = lane % kResolveCols, row_in_load = lane / kResolveCols; // 8 rows per load
+    for (uint32_t s0 = 0; s0 < s_count; s0 += kResolveCols) {
+#pragma unroll
+        for (uint32_t i = 0; i < 64u / (64u / kResolveCols); i++) {
+            const uint32_t row = row_in_load + i * (64u / kResolveCols);
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (rank0 + row < n_ranks && s0 + col < s_count) v = radiance[(size_t)(rank0 + row) * s_count + s0 + col];
+            tile[wave][row][col] = v;
+        }
+        __syncthreads();
+        const uint32_t cols = s_count - s0 < kResolveCols ? s_count - s0 : kResolveCols;
+        for (uint32_t c = 0; c < cols; c++) {
+            const float4 v = tile[wave][lane][c];
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+        }
+        __syncthreads();
     }
+    if (!owned) return;
     if (finish) {
         float inv = (float)F.spp;
         acc.x = acc.x / inv;
