@@ -270,13 +270,13 @@ static int tri_test(const float *v, const rt_ray *ray, float *t_out, float bary[
 
 /* ---- medium: deterministic free-flight sample ----------------------------- */
 static float medium_uniform(const rt_ray *ray, uint32_t prim) {
-    uint32_t h = orc_hash32(f2u(ray->d[2]));
-    h = orc_hash32(f2u(ray->d[1]) ^ h);
-    h = orc_hash32(f2u(ray->d[0]) ^ h);
-    h = orc_hash32(f2u(ray->o[2]) ^ h);
-    h = orc_hash32(f2u(ray->o[1]) ^ h);
-    h = orc_hash32(f2u(ray->o[0]) ^ h);
-    h = orc_hash32(prim ^ h);
+    const uint32_t k = 0x9E3779B1u; /* one multiply-xor step per word, one full mixing round */
+    uint32_t h = (prim ^ f2u(ray->d[2])) * k;
+    h = (h ^ f2u(ray->d[1])) * k;
+    h = (h ^ f2u(ray->d[0])) * k;
+    h = (h ^ f2u(ray->o[2])) * k;
+    h = (h ^ f2u(ray->o[1])) * k;
+    h = orc_hash32(h ^ f2u(ray->o[0]));
     return (float)(h >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
 

@@ -284,6 +284,18 @@ def test_rect_box_medium_known_answers():
     hit = h["prim"] == 0
     assert abs(hit.mean() - (1 - np.exp(-0.5 * 2))) < 0.02
     assert (h["t"][hit] > 4.0).all() and (h["t"][hit] < 6.0).all()
+    # scatter depths follow the exponential law: recover the uniform variate and test it for
+    # flatness and for independence between rays that differ in the last bits of one coordinate
+    rays["o"] = np.stack([np.float32(0.1) + np.arange(n, dtype=np.float32) * np.float32(2.0 ** -20),
+                          np.zeros(n, np.float32), np.full(n, -5.0, np.float32)], axis=1)
+    o2 = single(lambda s: s.add_medium(50.0, 0, sphere=((0, 0, 0), 1.0)))  # dense: every ray scatters
+    h = o2.intersect(rays)
+    assert (h["prim"] == 0).all()
+    depth = h["t"].astype(np.float64) - (5.0 - np.sqrt(1.0 - rays["o"][:, 0].astype(np.float64) ** 2))
+    u = np.exp(-50.0 * depth)
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1.0 / 12.0) < 0.005
+    assert (np.abs(np.histogram(u, bins=20, range=(0, 1))[0] / n - 0.05) < 0.01).all()
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.03 and abs(np.corrcoef(u[:-2], u[2:])[0, 1]) < 0.03
 
 
 # ---- structure ------------------------------------------------------------------------------------------
