@@ -175,7 +175,7 @@ def main():
                              info.device_bytes / 1e6)},
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
+        if world == 1 and os.path.exists(traffic_file):  # measured on whole-frame launches
             with open(traffic_file) as f:
                 out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
         if world == 1 and not args.no_cpu_baseline:
