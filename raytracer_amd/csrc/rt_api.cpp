@@ -331,7 +331,8 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     // primitives the plain shader does not cover by kind
     auto rare_prim = [&](const rt_prim_ref &pr) {
         const uint32_t kind = pr.kind & 0xffu;
-        return pr.xform != 0 || !(kind == RT_SPHERE || kind == RT_TRIANGLE || kind == RT_RECT || kind == RT_BOX);
+        return pr.xform != 0 ||
+               !(kind == RT_SPHERE || kind == RT_TRIANGLE || kind == RT_RECT || kind == RT_BOX || kind == RT_MEDIUM);
     };
     auto ref_of = [&](size_t i) {
         return nodes[i].primitive_count ? (rt::kLeafRef | nodes[i].child_offset) : record_of[i];
@@ -343,7 +344,8 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         if (pr.material >= s.materials.size()) return true; // intersection-only scene: never shaded
         const rt_material &m = s.materials[pr.material];
         if (m.texture >= s.textures.size()) return true;
-        if (!(m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_DIFFUSE_LIGHT))
+        if (!(m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_DIFFUSE_LIGHT ||
+              m.kind == RT_MAT_ISOTROPIC))
             return true;
         const rt_texture &t = s.textures[m.texture];
         return !(t.kind == RT_TEX_SOLID || (t.kind == RT_TEX_CHECKER && solid(t.a) && solid(t.b)));

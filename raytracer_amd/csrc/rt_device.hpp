@@ -25,8 +25,9 @@ struct LeafPrim {      // one entry per primitive, in leaf order (BVH::primitive
 
 constexpr uint32_t kLastInLeaf = 0x200u; // LeafPrim.kind: no further primitive in this leaf
 // LeafPrim.kind: a hit on this primitive needs the general shader (anything but a sphere,
-// triangle, rectangle or box without instance transform, carrying a Lambertian, metallic
-// or emissive material whose texture is a solid colour or a 3-D checker of solid colours)
+// triangle, rectangle, box or medium without instance transform, carrying a Lambertian,
+// metallic, emissive or isotropic material whose texture is a solid colour or a 3-D checker
+// of solid colours)
 constexpr uint32_t kRareShade = 0x400u;
 // LeafPrim.kind of a medium bounded by a sphere: geom is the sphere and index holds the bits
 // of -1 / density instead of a row of SceneDev::media
@@ -734,8 +735,9 @@ RT_DEV void prim_finalize(const SceneDev &S, const LeafPrim &lp, const Ray &ray,
     }
 }
 
-// prim_finalize for the hits the plain shader takes (no kRareShade): the four kinds without
-// instance transform, and no surface (u, v), which only image and uv-checker textures read.
+// prim_finalize for the hits the plain shader takes (no kRareShade): the four surface kinds
+// without instance transform and scattering inside a medium, and no surface (u, v), which
+// only image and uv-checker textures read.
 // Point, error bound and normal come out of the same arithmetic as above.
 RT_DEV void prim_finalize_plain(const SceneDev &S, const LeafPrim &lp, const Ray &ray, float t, float a0,
                                 float a1, float a2, Surf &out) {
@@ -749,6 +751,10 @@ RT_DEV void prim_finalize_plain(const SceneDev &S, const LeafPrim &lp, const Ray
         float4 sp = lp.geom;
         v3 c = mk(sp.x, sp.y, sp.z);
         sphere_surface<false>(ray.o - c, ray.d, c, sp.w, t, out);
+    } else if (kind == RT_MEDIUM) {
+        out.p = ray.o + ray.d * t;
+        out.perr = mk(0.0f, 0.0f, 0.0f);
+        out.n = mk(1.0f, 0.0f, 0.0f);
     } else if (kind == RT_BOX) {
         rt_box bx = S.boxes[lp.index];
         int face = (int)a0;

@@ -1114,7 +1114,7 @@ RT_DEV v3 texture_plain(const SceneDev &S, uint32_t tex, v3 p) {
 // Shading of one finished path segment: emit, or scatter into the next ray
 // (L.ray.o / L.ray.d) with the throughput updated.  Returns whether the path
 // continues.  PLAIN: the hit does not carry kBestRare (or is a miss), so only the
-// four common primitive kinds, the three materials and the two texture forms that
+// four common surface kinds and media, the four materials and the two texture forms that
 // flag leaves out can occur; the general code is the same computation with every
 // case present.
 template <bool PLAIN>
@@ -1161,6 +1161,8 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     } else if (m.kind == RT_MAT_METALLIC) {
         dir = reflect(d, nf) + rs * m.fuzz;
         if (!(dot(dir, nf) > 0.0f)) alive = false; // absorbed
+    } else if (m.kind == RT_MAT_ISOTROPIC) {
+        dir = rs;
     } else if (!PLAIN && m.kind == RT_MAT_DIELECTRIC) {
         float ratio = front ? 1.0f / m.ior : m.ior;
         float cos_t = sel_min(dot(-d, nf), 1.0f);
@@ -1181,8 +1183,6 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
             v3 par = nf * -sqrtf(fabsf(k));
             dir = perp + par;
         }
-    } else if (!PLAIN) { // RT_MAT_ISOTROPIC
-        dir = rs;
     }
     if (alive) {
         dir = normalize(dir);
@@ -1201,8 +1201,8 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
 // (queue entry, winning leaf slot, t, three primitive-specific values) in one of
 // the wave's two parking lists and its lane is refilled at once.  List 0 takes
 // misses and hits the plain shader covers, list 1 the hits that need the general
-// shader (textures with lookups or noise, dielectrics, media, transformed or
-// moving primitives).  When a list holds 64 records the whole wave shades them
+// shader (textures with lookups or noise, dielectrics, transformed or moving
+// primitives).  When a list holds 64 records the whole wave shades them
 // together: every lane of every shading instruction works, the short plain shader
 // runs for most rays, and the long general one runs once per 64 rays that need it
 // rather than whenever one ray of a wave does.  The lanes' traversal state is
