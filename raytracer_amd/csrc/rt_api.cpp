@@ -343,6 +343,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         if (rare_prim(pr)) return true;
         if (pr.material >= s.materials.size()) return true; // intersection-only scene: never shaded
         const rt_material &m = s.materials[pr.material];
+        if (m.kind == RT_MAT_DIELECTRIC) return false; // no texture
         if (m.texture >= s.textures.size()) return true;
         if (!(m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_DIFFUSE_LIGHT ||
               m.kind == RT_MAT_ISOTROPIC))

@@ -1149,8 +1149,10 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
 #endif
     if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
         rs = random_in_unit_sphere(rng);
-    if (PLAIN) tex = texture_plain(S, m.texture, h.p);
-    else if (m.kind != RT_MAT_DIELECTRIC) tex = texture_value(S, m.texture, h.u, h.v, h.p);
+    if (m.kind != RT_MAT_DIELECTRIC) {
+        if (PLAIN) tex = texture_plain(S, m.texture, h.p);
+        else tex = texture_value(S, m.texture, h.u, h.v, h.p);
+    }
     v3 dir = nf;
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
         radiance[local] = make_float4(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z, 0.0f);
@@ -1163,7 +1165,7 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
         if (!(dot(dir, nf) > 0.0f)) alive = false; // absorbed
     } else if (m.kind == RT_MAT_ISOTROPIC) {
         dir = rs;
-    } else if (!PLAIN && m.kind == RT_MAT_DIELECTRIC) {
+    } else if (m.kind == RT_MAT_DIELECTRIC) {
         float ratio = front ? 1.0f / m.ior : m.ior;
         float cos_t = sel_min(dot(-d, nf), 1.0f);
         float sin_t = sqrtf(1.0f - cos_t * cos_t);
