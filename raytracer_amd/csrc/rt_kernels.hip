@@ -183,6 +183,10 @@ struct Trav {
 // uniform.
 struct Blocks {
     uint32_t blk, off, n, stride;
+    // With a cursor the wave's first block is its static one and every further block is
+    // claimed from a counter the waves of the stream share (offset stride: right after the
+    // first blocks), so that a wave whose rays run long leaves its later blocks to others.
+    uint32_t *cursor = nullptr;
     RT_DEV bool more() const { return blk < n; }
     // Hands the next unread entries to the lanes that want one, in lane order; kNone
     // for a lane that gets none (the current block is used up first, so some lanes
@@ -195,7 +199,13 @@ struct Blocks {
         const uint32_t idx = (want && rank < avail) ? blk + off + rank : kNone;
         off += min((uint32_t)__popcll(m), avail);
         if (len != 0 && off >= len) {
-            blk += stride;
+            if (cursor) {
+                uint32_t c = 0;
+                if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 64u);
+                blk = stride + __builtin_amdgcn_readfirstlane(c);
+            } else {
+                blk += stride;
+            }
             off = 0;
         }
         return idx;
@@ -1414,7 +1424,11 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
     uint8_t *mine = scratch + (size_t)w * kWaveScratchBytes;
     BounceFeed feed{S, qin, qout, cout + shard * kCountStride, (size_t)shard * qin.cap, (size_t)shard * qout.cap,
-                    Blocks{(w / kShards) * 64, 0u, n, per_shard * 64}, bounce == last, seed, radiance,
+                    // blocks after a wave's first are claimed from the word next to the sub-queue's
+                    // size (zero at launch: counts are cleared once per batch)
+                    Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
+                           counts + ((size_t)bounce * kShards + shard) * kCountStride + 1},
+                    bounce == last, seed, radiance,
                     reinterpret_cast<float4 *>(mine), reinterpret_cast<float2 *>(mine + 2 * kParkSlots * 16),
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u};
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost

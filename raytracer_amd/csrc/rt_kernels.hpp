@@ -12,7 +12,8 @@ namespace rt {
 struct SceneDev;
 
 // A bounce queue is kShards independent sub-queues of `cap` entries each; the
-// tail counter of sub-queue s for bounce b is counts[(b * kShards + s) * kCountStride]
+// tail counter of sub-queue s for bounce b is counts[(b * kShards + s) * kCountStride],
+// the word after it the cursor from which the waves reading that sub-queue claim blocks
 // (one counter per 64-byte line).
 constexpr uint32_t kShards = 32;
 constexpr uint32_t kCountStride = 16;
