@@ -96,6 +96,10 @@ struct DeviceBuffers {
     float4 *radiance = nullptr;
     uint32_t *counts = nullptr;
     std::vector<void *> ws_allocs;
+    // one block cursor per stream the trace entry points were called on: launches on a stream
+    // run one after another, so they can share a word that is cleared in front of each
+    std::mutex cursor_lock;
+    std::map<hipStream_t, uint32_t *> cursors;
     // tables or per-pixel samples of the camera sampler (grown on demand)
     void *sampler_mem = nullptr;
     size_t sampler_bytes = 0;
@@ -252,6 +256,7 @@ void release(DeviceBuffers &db) {
     for (void *p : db.ws_allocs) (void)hipFree(p);
     db.allocs.clear();
     db.ws_allocs.clear();
+    db.cursors.clear();
     if (db.sampler_mem) (void)hipFree(db.sampler_mem);
     db.sampler_mem = nullptr;
     db.sampler_bytes = 0;
@@ -269,6 +274,23 @@ struct EventList {
         for (hipEvent_t e : all) (void)hipEventDestroy(e);
     }
 };
+
+// Clears the stream's block cursor and launches behind it; both are enqueued under the lock so
+// that two host threads sharing a stream cannot interleave them.
+template <class Launch>
+int with_cursor(DeviceBuffers &db, hipStream_t st, Launch launch) {
+    std::lock_guard<std::mutex> g(db.cursor_lock);
+    uint32_t *&c = db.cursors[st];
+    if (!c) {
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, rt::kCursorBytes));
+        db.allocs.push_back(p);
+        c = static_cast<uint32_t *>(p);
+    }
+    HIP_TRY(hipMemsetAsync(c, 0, rt::kCursorBytes, st));
+    HIP_TRY(launch(c));
+    return RT_OK;
+}
 
 // 0, or the reason the sampler options are not accepted (Stratified::new / ZeroTwo::new arguments)
 const char *sampler_problem(const rt_render_opts &o) {
@@ -734,8 +756,10 @@ int rt_intersect_dev(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        HIP_TRY(rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at, nullptr,
-                                     st));
+        if ((rc = with_cursor(*db, st, [&](uint32_t *cursor) {
+                 return rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at, nullptr, cursor, st);
+             })) != RT_OK)
+            return rc;
     }
     return RT_OK;
 }
@@ -750,8 +774,11 @@ int rt_intersect_count(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hi
     HIP_TRY(hipMemset(db->counters, 0, 32 * sizeof(unsigned long long)));
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        HIP_TRY(rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at,
-                                     db->counters, nullptr));
+        if ((rc = with_cursor(*db, nullptr, [&](uint32_t *cursor) {
+                 return rt::launch_intersect(db->dev, db->shape, d_rays + at, m, d_hits + at, db->counters, cursor,
+                                             nullptr);
+             })) != RT_OK)
+            return rc;
     }
     HIP_TRY(hipMemcpy(out, db->counters, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RT_OK;
@@ -765,7 +792,10 @@ int rt_occluded_dev(rt_scene *s, const rt_ray *d_rays, size_t n, uint8_t *d_out,
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
-        HIP_TRY(rt::launch_occluded(db->dev, db->shape, d_rays + at, m, d_out + at, st));
+        if ((rc = with_cursor(*db, st, [&](uint32_t *cursor) {
+                 return rt::launch_occluded(db->dev, db->shape, d_rays + at, m, d_out + at, cursor, st);
+             })) != RT_OK)
+            return rc;
     }
     return RT_OK;
 }

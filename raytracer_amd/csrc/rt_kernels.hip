@@ -187,6 +187,10 @@ struct Blocks {
     // claimed from a counter the waves of the stream share (offset stride: right after the
     // first blocks), so that a wave whose rays run long leaves its later blocks to others.
     uint32_t *cursor = nullptr;
+    // claim c (0, 1, ...) is block (first + c) * mul + add of the array: a counter may serve
+    // every mul-th block only, so that several counters share the claims of one array (one
+    // address takes about 90 atomics per microsecond)
+    uint32_t first = 0, mul = 1, add = 0;
     RT_DEV bool more() const { return blk < n; }
     // Hands the next unread entries to the lanes that want one, in lane order; kNone
     // for a lane that gets none (the current block is used up first, so some lanes
@@ -201,8 +205,8 @@ struct Blocks {
         if (len != 0 && off >= len) {
             if (cursor) {
                 uint32_t c = 0;
-                if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 64u);
-                blk = stride + __builtin_amdgcn_readfirstlane(c);
+                if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 1u);
+                blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
             } else {
                 blk += stride;
             }
@@ -534,12 +538,27 @@ struct HitFeed {
     RT_DEV void finish() {}
 };
 
+// A wave's share of a flat ray array: block w first; with cursors (kShards words, one per
+// 64-byte line, zero at launch) every further block is claimed, wave w drawing on counter
+// w % kShards, which serves the blocks b with b % kShards == w % kShards.
+RT_DEV Blocks flat_blocks(uint32_t n, uint32_t *cursors) {
+    const uint32_t w = wave_index(), total = wave_total();
+    Blocks b{w * 64, 0u, n, total * 64};
+    if (cursors && total % kShards == 0) {
+        b.cursor = cursors + (w % kShards) * kCountStride;
+        b.first = total / kShards;
+        b.mul = kShards;
+        b.add = w % kShards;
+    }
+    return b;
+}
+
 template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_intersect(
-    SceneDev S, const rt_ray *rays, uint32_t n, rt_hit *hits, unsigned long long *counters) {
+    SceneDev S, const rt_ray *rays, uint32_t n, rt_hit *hits, unsigned long long *counters, uint32_t *cursor) {
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
-    HitFeed feed{S, rays, hits, Blocks{wave_index() * 64, 0u, n, wave_total() * 64}, kNone};
+    HitFeed feed{S, rays, hits, flat_blocks(n, cursor), kNone};
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL_HIT);
     if (COUNT) flush_counters(cnt, counters);
 }
@@ -568,10 +587,10 @@ struct AnyFeed {
 // <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
 template <bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_occluded(
-    SceneDev S, const rt_ray *rays, uint32_t n, uint8_t *out) {
+    SceneDev S, const rt_ray *rays, uint32_t n, uint8_t *out, uint32_t *cursor) {
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
-    AnyFeed feed{rays, out, Blocks{wave_index() * 64, 0u, n, wave_total() * 64}, kNone};
+    AnyFeed feed{rays, out, flat_blocks(n, cursor), kNone};
     trace_stream<true, false, LDSN>(S, tv, feed, cnt);
 }
 
@@ -1427,7 +1446,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                     // blocks after a wave's first are claimed from the word next to the sub-queue's
                     // size (zero at launch: counts are cleared once per batch)
                     Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
-                           counts + ((size_t)bounce * kShards + shard) * kCountStride + 1},
+                           counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
                     bounce == last, seed, radiance,
                     reinterpret_cast<float4 *>(mine), reinterpret_cast<float2 *>(mine + 2 * kParkSlots * 16),
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u};
@@ -1565,31 +1584,31 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
     } while (0)
 
 hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n,
-                            rt_hit *hits, unsigned long long *counters, hipStream_t stream) {
+                            rt_hit *hits, unsigned long long *counters, uint32_t *cursor, hipStream_t stream) {
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     uint32_t blocks = (n + threads - 1) / threads;
     if (blocks > L.grid) blocks = L.grid;
     if (blocks == 0) return hipSuccess;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) {
-        if (counters) RT_LAUNCH((k_intersect<true, true>), blocks, threads, S, rays, n, hits, counters);
-        else RT_LAUNCH((k_intersect<false, true>), blocks, threads, S, rays, n, hits, counters);
+        if (counters) RT_LAUNCH((k_intersect<true, true>), blocks, threads, S, rays, n, hits, counters, cursor);
+        else RT_LAUNCH((k_intersect<false, true>), blocks, threads, S, rays, n, hits, counters, cursor);
     } else {
-        if (counters) RT_LAUNCH((k_intersect<true, false>), blocks, threads, S, rays, n, hits, counters);
-        else RT_LAUNCH((k_intersect<false, false>), blocks, threads, S, rays, n, hits, counters);
+        if (counters) RT_LAUNCH((k_intersect<true, false>), blocks, threads, S, rays, n, hits, counters, cursor);
+        else RT_LAUNCH((k_intersect<false, false>), blocks, threads, S, rays, n, hits, counters, cursor);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
-                           hipStream_t stream) {
+                           uint32_t *cursor, hipStream_t stream) {
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     uint32_t blocks = (n + threads - 1) / threads;
     if (blocks > L.grid) blocks = L.grid;
     if (blocks == 0) return hipSuccess;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
-    if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out);
-    else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out);
+    if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out, cursor);
+    else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out, cursor);
     return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ struct SceneDev;
 // (one counter per 64-byte line).
 constexpr uint32_t kShards = 32;
 constexpr uint32_t kCountStride = 16;
+constexpr size_t kCursorBytes = kShards * kCountStride * sizeof(uint32_t);
 
 // Structure of arrays so that a wave's 64 consecutive entries are 1 KiB
 // contiguous in each array.  Entry i of sub-queue s is element s * cap + i.
@@ -93,10 +94,12 @@ constexpr uint32_t kSpillLevels = 56;
 // Dynamic LDS of a trace workgroup (interior records for the LDS-resident shape + stacks).
 size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds);
 
+// cursor: kCursorBytes of device memory, zero when the kernel starts (kShards counters from
+// which the waves claim their ray blocks), or null for a static deal of the blocks
 hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n,
-                            rt_hit *hits, unsigned long long *counters, hipStream_t stream);
+                            rt_hit *hits, unsigned long long *counters, uint32_t *cursor, hipStream_t stream);
 hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
-                           hipStream_t stream);
+                           uint32_t *cursor, hipStream_t stream);
 // pixel samplers: F.pixel_samples holds the pixels first / spp ... (slot = pixel - first / spp)
 hipError_t launch_generate_rays(const FrameDev &F, const rt_camera &cam, uint64_t first, uint32_t n,
                                 rt_ray *rays, hipStream_t stream);
