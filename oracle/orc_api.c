@@ -247,6 +247,7 @@ static void *run_job(void *arg) {
             j->segments += n;
         }
     }
+    orc_thread_release();
     return NULL;
 }
 

@@ -99,6 +99,8 @@ uint32_t orc_tree_depth(const rt_linear_node *nodes, uint32_t n_nodes);
 void orc_camera_ray(const rt_camera *cam, float fx, float fy, float lu, float lv, float tu,
                     rt_ray *out);
 /* Camera sample of path (pixel, s): film offsets u[0], u[1], time u[2], lens u[3], u[4]. */
+/* frees what the calling thread cached (per-pixel samples) */
+void orc_thread_release(void);
 void orc_camera_sample(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, orc_rng *rng, float u[5]);
 void orc_path_setup(const rt_camera *cam, const rt_render_opts *opts, uint64_t path, orc_rng *rng,
                     rt_ray *ray);

@@ -402,8 +402,14 @@ static void pixel_samples(const rt_render_opts *o, uint64_t pixel, float *buf) {
     }
 }
 
+/* the calling thread's most recent pixel; a worker thread releases it before it ends */
+static __thread struct { float *buf; uint32_t cap; uint64_t pixel, seed; uint32_t sampler, arg, spp, width, valid; } g_pixel;
+void orc_thread_release(void) {
+    free(g_pixel.buf);
+    memset(&g_pixel, 0, sizeof g_pixel);
+}
 static void pixel_sampler_sample(const rt_render_opts *o, uint32_t px, uint32_t py, uint32_t s, float u[5]) {
-    static __thread struct { float *buf; uint32_t cap; uint64_t pixel, seed; uint32_t sampler, arg, spp, width, valid; } c;
+#define c g_pixel
     const uint64_t pixel = (uint64_t)py * o->width + px;
     if (!c.valid || c.pixel != pixel || c.seed != o->seed || c.sampler != o->sampler || c.arg != o->sampler_arg ||
         c.spp != o->spp || c.width != o->width) {
@@ -418,6 +424,7 @@ static void pixel_sampler_sample(const rt_render_opts *o, uint32_t px, uint32_t 
     }
     for (int k = 0; k < 5; k++) u[k] = c.buf[(size_t)k * o->spp + s];
 }
+#undef c
 
 /* 0 when the options name a sampler and arguments the samplers accept */
 int orc_sampler_check(const rt_render_opts *o) {
