@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of rt_intersect_dev / rt_occluded_dev: primary rays (coherent)
 and cosine-distributed bounce rays (incoherent) on one scene, rays resident in
-HBM.  usage: trace_bench.py [scene] [log2 rays] [scene kwargs as k=v]"""
+HBM.  usage: trace_bench.py [scene] [log2 rays] [scene kwargs as k=v] [--orders]"""
 import json
 import os
 import sys
@@ -17,7 +17,7 @@ from raytracer_amd import abi, lib, scenes
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "week"
     log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-    kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[3:])}
+    kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[3:] if "=" in a)}
     sd, camf = scenes.BUILDERS[name](**kw)
     fr = sd.freeze()
     scene = lib.Scene(fr)
@@ -86,6 +86,38 @@ def main():
                       "prims_per_ray": round(float(cnt[1:].sum()) / m, 2)}
     ms = timed(lambda: scene.occluded_dev(b_rays.data_ptr(), m, d_occ.data_ptr(), stream))
     out["bounce1_any_hit"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+    # the same bounce rays in random order and sorted by the Morton code of their origin: what
+    # the order of a ray array is worth
+    if "--orders" in sys.argv:
+        perm = torch.randperm(m, device="cuda", generator=g)
+        shuffled = b_rays[perm].contiguous()
+        ms = timed(lambda: scene.intersect_dev(shuffled.data_ptr(), m, d_hits.data_ptr(), stream))
+        out["bounce1_shuffled"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+        lo, hi = b_rays[:, 0:3].amin(0), b_rays[:, 0:3].amax(0)
+        q = ((b_rays[:, 0:3] - lo) / (hi - lo).clamp_min(1e-20) * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+        def spread(x):
+            x = (x | (x << 16)) & 0x030000FF
+            x = (x | (x << 8)) & 0x0300F00F
+            x = (x | (x << 4)) & 0x030C30C3
+            return (x | (x << 2)) & 0x09249249
+        code = (spread(q[:, 2]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 0])
+        ordered = b_rays[torch.argsort(code)].contiguous()
+        ms = timed(lambda: scene.intersect_dev(ordered.data_ptr(), m, d_hits.data_ptr(), stream))
+        out["bounce1_origin_sorted"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+        # coarse cells only (32 per axis), random order inside a cell
+        q5 = q >> 5
+        code5 = (spread(q5[:, 2]) << 2) | (spread(q5[:, 1]) << 1) | spread(q5[:, 0])
+        coarse = shuffled[torch.argsort(code5[perm], stable=True)].contiguous()
+        ms = timed(lambda: scene.intersect_dev(coarse.data_ptr(), m, d_hits.data_ptr(), stream))
+        out["bounce1_cell32_sorted"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+        # origin cells of 128 per axis
+        q7 = q >> 3
+        code7 = (spread(q7[:, 2]) << 2) | (spread(q7[:, 1]) << 1) | spread(q7[:, 0])
+        mid = shuffled[torch.argsort(code7[perm], stable=True)].contiguous()
+        ms = timed(lambda: scene.intersect_dev(mid.data_ptr(), m, d_hits.data_ptr(), stream))
+        out["bounce1_cell128_sorted"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
+        del shuffled, ordered, coarse, mid
     # host-pointer entry points: PCIe staging included (rays up, hits down)
     import time
     h_rays = b_rays[:1 << 22].cpu().numpy().view(abi.ray_dtype).reshape(-1)
