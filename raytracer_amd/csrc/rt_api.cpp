@@ -557,7 +557,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         db.shape.grid = std::max(8u, (uint32_t)prop.multiProcessorCount * per_cu / 8 * 8);
     }
     static_assert(rt::kShards == 32, "grid rounding above assumes 32 sub-queues");
-    const size_t scratch_bytes = (size_t)rt::bounce_waves(db.shape) * rt::kWaveScratchBytes;
+    const size_t scratch_bytes = (size_t)rt::bounce_waves(db.shape) * std::max(rt::kWaveScratchBytes, rt::kWaveLoopBytes);
     HIP_TRY(hipMalloc(&p, scratch_bytes));
     db.allocs.push_back(p);
     db.bounce_scratch = static_cast<uint8_t *>(p);
@@ -1134,6 +1134,20 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     const uint32_t batch_paths = (uint32_t)batch_paths64;
     if ((rc = grow_workspace(*db, batch_paths ? batch_paths : 1, o->max_depth)) != RT_OK) return rc;
 
+    // Once few rays are left one launch follows them to the end of their paths
+    // (launch_bounce_loop): a launch per bounce is the better deal for full queues (less state
+    // per ray, rays of one depth shade together) and a floor of ~0.1 ms per bounce under the
+    // frame time for nearly empty ones.  The host looks at the queue size before bounces 2, 4,
+    // 8, 16, ... (one small synchronising copy each) and switches below `loop_below` rays.
+    // RT355_LOOP_FROM=<bounce> fixes the bounce instead, RT355_LOOP_BELOW=<rays> the threshold
+    // (0: never), for tests and experiments.
+    uint32_t loop_from = 0xffffffffu;
+    uint64_t loop_below = db->shape.lds_nodes ? (8u << 20) : (2u << 20);
+    if (const char *e = getenv("RT355_LOOP_FROM")) {
+        loop_from = (uint32_t)atoi(e);
+        loop_below = 0;
+    }
+    if (const char *e = getenv("RT355_LOOP_BELOW")) loop_below = strtoull(e, nullptr, 10);
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
     EventList events; // destroyed on every way out
@@ -1165,11 +1179,27 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 ev.push_back(e0);
                 ev.push_back(e1);
             }
-            HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
-                                      db->counts, b, o->max_depth - 1, o->seed, db->radiance,
-                                      db->bounce_scratch, want_counters ? db->counters : nullptr, st));
+            bool rest = b >= loop_from && b + 1 < o->max_depth;
+            if (!rest && loop_below && b >= 2 && (b & (b - 1)) == 0 && b + 1 < o->max_depth) {
+                uint32_t sizes[rt::kShards * rt::kCountStride];
+                HIP_TRY(hipMemcpyAsync(sizes, db->counts + (size_t)b * rt::kShards * rt::kCountStride, sizeof sizes,
+                                       hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                uint64_t queued = 0;
+                for (uint32_t k = 0; k < rt::kShards; k++) queued += sizes[k * rt::kCountStride];
+                rest = queued < loop_below;
+            }
+            if (rest)
+                HIP_TRY(rt::launch_bounce_loop(db->dev, db->shape, db->q[b & 1], db->counts, b, o->max_depth - 1,
+                                               o->seed, db->radiance, db->bounce_scratch,
+                                               want_counters ? db->counters : nullptr, st));
+            else
+                HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
+                                          db->counts, b, o->max_depth - 1, o->seed, db->radiance,
+                                          db->bounce_scratch, want_counters ? db->counters : nullptr, st));
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
             launches++;
+            if (rest) break;
         }
         if (filtered) {
             HIP_TRY(rt::launch_film(F, film, db->radiance, s0, sc, reinterpret_cast<float4 *>(d_rgba), st));

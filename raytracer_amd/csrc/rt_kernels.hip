@@ -249,7 +249,8 @@ struct Blocks {
 // bool turn(Trav &, bool free): for free lanes, consume the finished ray if
 // L.has_ray, then load the next ray or clear has_ray; returns true on lanes that
 // received a ray (it may save the whole of Trav to memory and reload it), and
-// void finish(), called once when every ray of the wave has been consumed.
+// bool drain(), called when nothing is left to hand out: true if the feed found more after
+// all (only a feed that turns results into new rays), and void finish(), called once at the end.
 template <bool ANY, bool COUNT, bool LDSN, class Feed>
 RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt,
                          const uint32_t refill_lanes = refill_lanes_of<LDSN>()) {
@@ -342,6 +343,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                 })
                 if (__ballot(L.has_ray) == 0) {
                     if (feed.more()) continue; // only dead entries came: ask again
+                    if (feed.drain()) continue; // a feed that makes rays of its own results
                     break;
                 }
             }
@@ -535,6 +537,7 @@ struct HitFeed {
         }
         return free && L.has_ray;
     }
+    RT_DEV bool drain() { return false; }
     RT_DEV void finish() {}
 };
 
@@ -581,6 +584,7 @@ struct AnyFeed {
         }
         return free && L.has_ray;
     }
+    RT_DEV bool drain() { return false; }
     RT_DEV void finish() {}
 };
 
@@ -1403,6 +1407,7 @@ struct BounceFeed {
         return fresh;
     }
 
+    RT_DEV bool drain() { return false; }
     // after the last ray of the stream: shade what is still parked
     RT_DEV void finish() {
         __threadfence_block();
@@ -1454,6 +1459,263 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
     PROF(cnt.p[7] = feed.prof_shade;)
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- the rest of the path in one launch ------------------------------------------------------------
+// Late bounces carry few rays, and a launch lasts a wave's whole chain fetch -> traverse ->
+// park -> shade -> push however few it has: fifty such launches are a floor under the frame
+// time that matters when the frame is split over several GPUs.  This feed does not hand a
+// bounce's survivors to the next launch: a wave keeps the survivors of its own shading batches
+// in a ring of its own and feeds them back to its free lanes, so one launch takes the rays
+// of bounce `bounce0` to the end of their paths.  Per wave, in global memory:
+//   parking lists  2 x kParkSlots x 5 float4: ray, hit and path state of a finished segment
+//   lane area      64 x 2 float4: path state of the segment a lane is tracing (throughput,
+//                  generator, path id, pixel slot, depth), written when the lane is fed
+//   ring           kRingSlots x 4 float4: segments waiting for a lane, first in first out
+//   save area      as in BounceFeed
+// A wave never holds more than 64 + 2 x 127 + 128 segments, so the ring cannot overflow.
+constexpr uint32_t kRingSlots = 512;
+constexpr size_t kLoopParkBytes = 2 * kParkSlots * 5 * 16, kLoopLaneBytes = 64 * 2 * 16,
+                 kLoopRingBytes = kRingSlots * 4 * 16;
+static_assert(kWaveLoopBytes == kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes + kSaveWords * 64 * 4,
+              "per-wave memory of the loop kernel");
+
+struct LoopFeed {
+    const SceneDev &S;
+    const Queue &qin;
+    size_t in_base;
+    Blocks blocks;
+    uint32_t *counts; // queue sizes by bounce: here only statistics (segments traced per bounce)
+    uint32_t shard, bounce0, last;
+    uint64_t seed;
+    float4 *radiance;
+    float4 *park;   // [list][slot][5]
+    float4 *lane_c; // throughput.rgb, generator state low word
+    uint4 *lane_d;  // generator state high word, path id, pixel slot, depth
+    float4 *ring;   // [slot][4]: a, b, c as in Queue, d = lane_d
+    uint32_t *save;
+    uint32_t parked[2];
+    uint32_t ring_head, ring_count, turns;
+
+    RT_DEV bool more() const { return ring_count != 0 || blocks.more(); }
+
+    template <bool PLAIN>
+    RT_DEV void shade_batch(uint32_t first, uint32_t count) {
+        const uint32_t lane = threadIdx.x & 63;
+        bool alive = false;
+        Lane P;
+        v3 beta = mk(0.0f, 0.0f, 0.0f);
+        Rng rng{0, 0};
+        uint32_t gpath = 0, local = kDead, depth = 0;
+        if (lane < count) {
+            const float4 *r = park + (size_t)(first + lane) * 5;
+            const float4 p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3], p4 = r[4];
+            P.ray.o = mk(p0.x, p0.y, p0.z);
+            P.ray.time = p0.w;
+            P.ray.d = mk(p1.x, p1.y, p1.z);
+            P.ray.t_max = p1.w;
+            P.best = __float_as_uint(p2.x);
+            P.a0 = p2.y;
+            P.a1 = p2.z;
+            P.a2 = p2.w;
+            P.has_ray = true;
+            beta = mk(p3.x, p3.y, p3.z);
+            gpath = __float_as_uint(p4.y);
+            local = __float_as_uint(p4.z);
+            depth = __float_as_uint(p4.w);
+            rng.state = ((uint64_t)__float_as_uint(p4.x) << 32) | __float_as_uint(p3.w);
+            rng.inc = (((seed << 32) + gpath) << 1) | 1u;
+            alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && depth < last;
+        }
+        // survivors join the ring as segments of the next bounce
+        const uint64_t mask = __ballot(alive);
+        if (mask) {
+            if (alive) {
+                float4 *e = ring + (size_t)((ring_head + ring_count + lane_rank(mask)) % kRingSlots) * 4;
+                e[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
+                e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, __uint_as_float(local));
+                e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
+                e[3] = make_float4(__uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float(gpath),
+                                   __uint_as_float(local), __uint_as_float(depth + 1));
+            }
+            ring_count += (uint32_t)__popcll(mask);
+            // segments per bounce, where the per-bounce kernels keep their queue sizes
+            uint64_t todo = mask;
+            while (todo) {
+                const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t dd = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)leader);
+                const uint64_t same = __ballot(alive && depth == dd);
+                if (lane == leader)
+                    atomicAdd(&counts[((size_t)(dd + 1) * kShards + shard) * kCountStride], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+
+    RT_DEV void shade_lists(uint32_t at_least) {
+        while (parked[0] >= at_least && parked[0] != 0) {
+            const uint32_t count = parked[0] < 64u ? parked[0] : 64u;
+            parked[0] -= count;
+            shade_batch<true>(parked[0], count);
+        }
+        while (parked[1] >= at_least && parked[1] != 0) {
+            const uint32_t count = parked[1] < 64u ? parked[1] : 64u;
+            parked[1] -= count;
+            shade_batch<false>(kParkSlots + parked[1], count);
+        }
+    }
+
+    RT_DEV bool turn(Trav &T, bool free) {
+        Lane &L = T.L;
+        const uint32_t lane = threadIdx.x & 63;
+        if (++turns > (1u << 24)) { // cannot happen; keeps a wave from spinning forever if it did
+            ring_count = 0;
+            blocks.blk = blocks.n;
+        }
+        // park the finished segments, whole
+        const bool finished = free && L.has_ray;
+        const bool general = L.best != RT_MISS && (L.best & kBestRare) != 0;
+        const uint64_t m0 = __ballot(finished && !general), m1 = __ballot(finished && general);
+        if (finished) {
+            const uint32_t slot = general ? kParkSlots + parked[1] + lane_rank(m1) : parked[0] + lane_rank(m0);
+            float4 *r = park + (size_t)slot * 5;
+            const uint4 d4 = lane_d[lane];
+            r[0] = make_float4(L.ray.o.x, L.ray.o.y, L.ray.o.z, L.ray.time);
+            r[1] = make_float4(L.ray.d.x, L.ray.d.y, L.ray.d.z, L.ray.t_max);
+            r[2] = make_float4(__uint_as_float(L.best), L.a0, L.a1, L.a2);
+            r[3] = lane_c[lane];
+            r[4] = make_float4(__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w));
+        }
+        parked[0] += (uint32_t)__popcll(m0);
+        parked[1] += (uint32_t)__popcll(m1);
+        if (parked[0] >= 64 || parked[1] >= 64) {
+            const bool any_busy = __ballot(T.cur != kNone) != 0;
+            uint32_t *sv = save + lane;
+            if (any_busy) {
+                sv[0 * 64] = __float_as_uint(L.ray.o.x); sv[1 * 64] = __float_as_uint(L.ray.o.y);
+                sv[2 * 64] = __float_as_uint(L.ray.o.z); sv[3 * 64] = __float_as_uint(L.ray.d.x);
+                sv[4 * 64] = __float_as_uint(L.ray.d.y); sv[5 * 64] = __float_as_uint(L.ray.d.z);
+                sv[6 * 64] = __float_as_uint(L.ray.t_max); sv[7 * 64] = __float_as_uint(L.ray.time);
+                sv[8 * 64] = L.best; sv[9 * 64] = __float_as_uint(L.a0);
+                sv[10 * 64] = __float_as_uint(L.a1); sv[11 * 64] = __float_as_uint(L.a2);
+                sv[12 * 64] = __float_as_uint(T.inv.x); sv[13 * 64] = __float_as_uint(T.inv.y);
+                sv[14 * 64] = __float_as_uint(T.inv.z); sv[15 * 64] = T.cur;
+                sv[16 * 64] = T.sp;
+            }
+            asm volatile("" ::: "memory");
+            __threadfence_block();
+            shade_lists(64);
+            asm volatile("" ::: "memory");
+            if (any_busy) {
+                L.ray.o = mk(__uint_as_float(sv[0 * 64]), __uint_as_float(sv[1 * 64]), __uint_as_float(sv[2 * 64]));
+                L.ray.d = mk(__uint_as_float(sv[3 * 64]), __uint_as_float(sv[4 * 64]), __uint_as_float(sv[5 * 64]));
+                L.ray.t_max = __uint_as_float(sv[6 * 64]);
+                L.ray.time = __uint_as_float(sv[7 * 64]);
+                L.best = sv[8 * 64];
+                L.a0 = __uint_as_float(sv[9 * 64]);
+                L.a1 = __uint_as_float(sv[10 * 64]);
+                L.a2 = __uint_as_float(sv[11 * 64]);
+                T.inv = mk(__uint_as_float(sv[12 * 64]), __uint_as_float(sv[13 * 64]), __uint_as_float(sv[14 * 64]));
+                T.cur = sv[15 * 64];
+                T.sp = sv[16 * 64];
+            } else {
+                L.ray.o = L.ray.d = T.inv = mk(0.0f, 0.0f, 0.0f);
+                L.ray.t_max = L.ray.time = L.a0 = L.a1 = L.a2 = 0.0f;
+                L.best = RT_MISS;
+                T.cur = kNone;
+                T.sp = 0;
+            }
+        }
+        // ring entries written by other lanes are read below
+        asm volatile("" ::: "memory");
+        __threadfence_block();
+        // next segments: the ring first, then unread rays of the queue
+        const uint64_t want = __ballot(free);
+        const uint32_t rank = lane_rank(want);
+        const uint32_t from_ring = min((uint32_t)__popcll(want), ring_count);
+        const bool ring_lane = free && rank < from_ring;
+        const uint32_t next = blocks.take(free && !ring_lane);
+        bool fresh = false;
+        if (free) {
+            L.has_ray = false;
+            float4 qa, qb, qc;
+            uint4 qd = make_uint4(0u, 0u, 0u, 0u);
+            bool got = false;
+            if (ring_lane) {
+                const float4 *e = ring + (size_t)((ring_head + rank) % kRingSlots) * 4;
+                qa = e[0];
+                qb = e[1];
+                qc = e[2];
+                const float4 d4 = e[3];
+                qd = make_uint4(__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w));
+                got = true;
+            } else if (next != kNone) {
+                qa = qin.a[in_base + next];
+                qb = qin.b[in_base + next];
+                if (__float_as_uint(qb.w) != kDead) {
+                    qc = qin.c[in_base + next];
+                    const uint2 d2 = qin.d[in_base + next];
+                    qd = make_uint4(d2.x, d2.y, __float_as_uint(qb.w), bounce0);
+                    got = true;
+                }
+            }
+            if (got) {
+                L.ray.o = mk(qa.x, qa.y, qa.z);
+                L.ray.time = qa.w;
+                L.ray.d = mk(qb.x, qb.y, qb.z);
+                L.ray.t_max = kInf;
+                lane_c[lane] = qc;
+                lane_d[lane] = qd;
+                L.has_ray = true;
+                fresh = true;
+            }
+        }
+        ring_head = (ring_head + from_ring) % kRingSlots;
+        ring_count -= from_ring;
+        return fresh;
+    }
+
+    // nothing in the lanes, the ring or the queue: the paths parked in incomplete batches go on
+    RT_DEV bool drain() {
+        asm volatile("" ::: "memory");
+        __threadfence_block();
+        shade_lists(1);
+        asm volatile("" ::: "memory");
+        __threadfence_block();
+        return ring_count != 0;
+    }
+    RT_DEV void finish() {}
+};
+
+// Bounce `bounce` and every later one of the paths queued for it, in one launch (LoopFeed).
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_bounce_loop(
+    SceneDev S, Queue qin, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
+    uint8_t *scratch, unsigned long long *counters) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
+    const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
+    uint32_t longest = my_count;
+    for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
+    const uint32_t n_chunks = kShards * ((longest + 63) / 64);
+    if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
+    Counters cnt = {};
+    const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
+    const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
+    uint8_t *mine = scratch + (size_t)w * kWaveLoopBytes;
+    LoopFeed feed{S, qin, (size_t)shard * qin.cap,
+                  Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
+                         counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
+                  counts, shard, bounce, last, seed, radiance,
+                  reinterpret_cast<float4 *>(mine),
+                  reinterpret_cast<float4 *>(mine + kLoopParkBytes),
+                  reinterpret_cast<uint4 *>(mine + kLoopParkBytes + 64 * 16),
+                  reinterpret_cast<float4 *>(mine + kLoopParkBytes + kLoopLaneBytes),
+                  reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
+                  {0u, 0u}, 0u, 0u, 0u};
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -1680,6 +1942,29 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
                       scratch, counters);
         else
             RT_LAUNCH((k_bounce<false, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
+                      scratch, counters);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bounce_loop(const SceneDev &S, const LaunchShape &L, const Queue &qin, uint32_t *counts,
+                              uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance, uint8_t *scratch,
+                              unsigned long long *counters, hipStream_t stream) {
+    const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
+    const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
+    if (L.lds_nodes) {
+        if (counters)
+            RT_LAUNCH((k_bounce_loop<true, true>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance, scratch,
+                      counters);
+        else
+            RT_LAUNCH((k_bounce_loop<false, true>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
+                      scratch, counters);
+    } else {
+        if (counters)
+            RT_LAUNCH((k_bounce_loop<true, false>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
+                      scratch, counters);
+        else
+            RT_LAUNCH((k_bounce_loop<false, false>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
                       scratch, counters);
     }
     return hipGetLastError();

@@ -114,11 +114,19 @@ constexpr size_t kWaveScratchBytes = 2 * kParkSlots * 24 + kSaveWords * 64 * 4;
 // Workgroups of the global-memory trace kernels that fit on one CU together with this much
 // dynamic LDS each (the smallest answer over the kernels, from the runtime's occupancy query).
 hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu);
-// waves of the bounce grid (scratch must hold kWaveScratchBytes for each)
+// Per-wave memory of the kernel that follows paths to their end in one launch (see LoopFeed).
+constexpr size_t kWaveLoopBytes = 2 * kParkSlots * 5 * 16 + 64 * 2 * 16 + 512 * 4 * 16 + kSaveWords * 64 * 4;
+// waves of the bounce grid (scratch must hold max(kWaveScratchBytes, kWaveLoopBytes) for each)
 uint32_t bounce_waves(const LaunchShape &L);
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
                          uint8_t *scratch, unsigned long long *counters, hipStream_t stream);
+// Bounce `bounce` and all later ones of the paths queued in qin (sizes at
+// counts[(bounce * kShards + s) * kCountStride]); writes the number of segments traced at each
+// later bounce where launch_bounce would have left its queue sizes.
+hipError_t launch_bounce_loop(const SceneDev &S, const LaunchShape &L, const Queue &qin, uint32_t *counts,
+                              uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance, uint8_t *scratch,
+                              unsigned long long *counters, hipStream_t stream);
 // Film::new's table of filter values (film.rs:99-113), passed to the film kernel by value.
 struct FilterDev {
     float w[256];

@@ -255,3 +255,32 @@ def test_stack_levels_beyond_lds(monkeypatch, nodes, scene_cache):
     img, st = g.render(cam(96, 64), lib.render_opts(96, 64, 4, 20, seed=2))
     ref_img, rst = o.render(cam(96, 64), orc.render_opts(96, 64, 4, 20, seed=2))
     assert img.tobytes() == ref_img.tobytes() and st.segments == rst.segments
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["week", "cornell", "random"])
+@pytest.mark.parametrize("loop_from", [0, 1, 4])
+def test_paths_followed_in_one_launch(monkeypatch, scene_cache, scene_name, loop_from):
+    """From bounce `loop_from` on, one launch follows the paths to their end (a wave feeds the
+    survivors of its shading batches back to its own lanes): same image, same segments per
+    bounce and same traversal counters as one launch per bounce, and as the oracle."""
+    _, cam, fr = scene_cache(scene_name)
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp, depth = 160, 96, 3, 50
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
+    monkeypatch.setenv("RT355_LOOP_BELOW", "0")  # one launch per bounce
+    base, bst = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
+    monkeypatch.delenv("RT355_LOOP_BELOW")
+    auto, ast = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5))  # the library decides (small frame)
+    assert ast.trace_launches < depth and auto.tobytes() == base.tobytes() and ast.segments == bst.segments
+    monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
+    img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
+    assert st.trace_launches == loop_from + 1 and bst.trace_launches == depth
+    assert img.tobytes() == ref.tobytes() == base.tobytes()
+    assert st.segments == rst.segments and list(st.bounce_rays) == list(bst.bounce_rays)
+    assert st.nodes_visited == rst.nodes_visited and list(st.prims_tested) == list(rst.prims_tested)
+    # depth limits: the last bounce allowed, and a limit of one
+    for d in (1, 2, loop_from + 2):
+        a, sa = g.render(cam(w, h), lib.render_opts(w, h, spp, d, seed=5))
+        b, sb = o.render(cam(w, h), orc.render_opts(w, h, spp, d, seed=5))
+        assert a.tobytes() == b.tobytes() and sa.segments == sb.segments
