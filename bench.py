@@ -14,11 +14,13 @@ into a zeroed full-size framebuffer and one RCCL reduce(sum) to rank 0 ends the
 frame: total work is fixed, so scaling is "strong".
 
 Extra objects on the JSON line:
-  roofline     -- the bounce kernel (k_bounce): algorithmic bytes of all ray
-                  segments of a frame (traversal counters of an untimed counting
-                  frame; identical to the oracle's) over the summed duration of
-                  the frame's bounce launches, measured with HIP events recorded
-                  on the launch stream inside the timed steps.
+  roofline     -- the bounce kernels (k_bounce: one launch per bounce while the
+                  queue is large; k_bounce_loop: one launch for all later bounces):
+                  algorithmic bytes of all ray segments of a frame (traversal
+                  counters of an untimed counting frame; identical to the oracle's)
+                  over the summed duration of the frame's bounce launches, measured
+                  with HIP events recorded on the launch stream inside the timed
+                  steps.
   cpu_baseline -- the CPU oracle (a port of the reference algorithm, not the
                   product) timed on the host cores on a bounded sample.
 """
@@ -165,7 +167,7 @@ def main():
                                                            info.n_nodes),
                        "sharding": "32x32 tiles round-robin over ranks, one reduce(sum) per frame",
                        "ray_segments_per_frame": int(segments / args.steps)},
-            "roofline": {"kernel": "k_bounce", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "k_bounce + k_bounce_loop", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes / max(launches_per_frame, 1)),
