@@ -173,8 +173,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes / max(launches_per_frame, 1)),
                          "avg_launch_ms": round(per_launch_ms, 4),
                          "launches_per_frame": launches_per_frame,
-                         "note": "scene (%.1f MB) is L2/Infinity-Cache resident; bytes are algorithmic" % (
-                             info.device_bytes / 1e6)},
+                         "note": "tree and primitive tables are LDS / L2 resident; bytes are algorithmic"},
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.exists(traffic_file):  # measured on whole-frame launches

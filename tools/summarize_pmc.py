@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter CSVs per kernel and derives the ratios quoted in the
-design notes.  usage: summarize_pmc.py <dir> [kernel substring] [--traffic out.json]
+design notes.  usage: summarize_pmc.py <dir> [kernel substrings, comma separated] [--traffic out.json]
 
 HBM traffic per launch = (FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024) / dispatches:
 on gfx950 FETCH_SIZE tallies the 128-byte requests of a 16-B-per-lane streaming read
@@ -14,13 +14,14 @@ import sys
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 root = args[0]
-match = args[1] if len(args) > 1 else "k_bounce<false"
+match = args[1] if len(args) > 1 else "k_bounce<false,k_bounce_loop<false"  # comma separated substrings
+wanted = match.split(",")
 traffic_out = sys.argv[sys.argv.index("--traffic") + 1] if "--traffic" in sys.argv else None
 tot = collections.defaultdict(float)
 disp = collections.defaultdict(set)
 for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if match not in r["Kernel_Name"]:
+        if not any(w in r["Kernel_Name"] for w in wanted):
             continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"])
         disp[r["Counter_Name"]].add(r["Dispatch_Id"])
