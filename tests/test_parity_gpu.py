@@ -284,3 +284,28 @@ def test_paths_followed_in_one_launch(monkeypatch, scene_cache, scene_name, loop
         a, sa = g.render(cam(w, h), lib.render_opts(w, h, spp, d, seed=5))
         b, sb = o.render(cam(w, h), orc.render_opts(w, h, spp, d, seed=5))
         assert a.tobytes() == b.tobytes() and sa.segments == sb.segments
+
+
+@pytest.mark.gpu
+def test_one_launch_kernel_with_film_sampler_and_shards(monkeypatch, scene_cache):
+    """The kernel that follows paths to their end under everything else a render can ask for:
+    a reconstruction filter, a low-discrepancy sampler, several sample batches and tile shards,
+    with trees read from LDS and from global memory."""
+    from tests.test_film_cpu import FILTERS
+    _, cam, fr = scene_cache("week")
+    o = orc.OracleScene(fr)
+    w, h, spp = 96, 64, 4
+    kw = dict(seed=2, filter=FILTERS["mitchell"], sampler=abi.RT_SAMPLER_SOBOL)
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, 30, **kw))
+    for nodes in ("lds", "global"):
+        if nodes == "global":
+            monkeypatch.setenv("RT355_NODES", "global")
+        g = lib.Scene(fr)
+        for loop_from in (1, 3):
+            monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
+            img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, 30, max_paths=6 * 1024 * 2, **kw))
+            assert st.batches == 2 and img.tobytes() == ref.tobytes() and st.segments == rst.segments
+        parts = [g.render(cam(w, h), lib.render_opts(w, h, spp, 30, seed=2, shard=(k, 3)))[0] for k in range(3)]
+        whole, _ = o.render(cam(w, h), orc.render_opts(w, h, spp, 30, seed=2))
+        assert (parts[0][..., :3] + parts[1][..., :3] + parts[2][..., :3]).tobytes() == whole[..., :3].tobytes()
+        g.close()
