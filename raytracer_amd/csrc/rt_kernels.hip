@@ -1671,8 +1671,10 @@ struct LoopFeed {
                 fresh = true;
             }
         }
-        ring_head = (ring_head + from_ring) % kRingSlots;
         ring_count -= from_ring;
+        // an empty ring starts over at slot 0: the same few kilobytes stay in cache instead of
+        // the head walking through all kRingSlots
+        ring_head = ring_count ? (ring_head + from_ring) % kRingSlots : 0u;
         return fresh;
     }
 
