@@ -1475,6 +1475,9 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 //   ring           kRingSlots x 4 float4: segments waiting for a lane, first in first out
 //   save area      as in BounceFeed
 // A wave never holds more than 64 + 2 x 127 + 128 segments, so the ring cannot overflow.
+#ifndef RT_LOOP_REFILL_LANES
+#define RT_LOOP_REFILL_LANES 24
+#endif
 constexpr uint32_t kRingSlots = 512;
 constexpr size_t kLoopParkBytes = 2 * kParkSlots * 5 * 16, kLoopLaneBytes = 64 * 2 * 16,
                  kLoopRingBytes = kRingSlots * 4 * 16;
@@ -1717,7 +1720,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   reinterpret_cast<float4 *>(mine + kLoopParkBytes + kLoopLaneBytes),
                   reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
                   {0u, 0u}, 0u, 0u, 0u};
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
 }
 
