@@ -3,7 +3,7 @@
 // bounds, tree builders on several threads, flattening; no GPU is touched) and runs the CPU
 // oracle on the same description (build, closest hit, any hit, a small render with every
 // sampler and a filter).  Also feeds the validator malformed descriptions.
-// Built and run by tools/sanitize/run.sh.
+// Built and run by tests/sanitize/run.sh.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

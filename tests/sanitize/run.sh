@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host code of librt355 and the whole CPU oracle under AddressSanitizer + UBSan (CPU only:
 # the device code is compiled as usual and never runs here).
-# usage: tools/sanitize/run.sh [thread]     (thread: ThreadSanitizer instead)
+# usage: tests/sanitize/run.sh [thread]     (thread: ThreadSanitizer instead)
 set -e
 MODE=${1:-address}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -21,6 +21,6 @@ done
   $HSAN \
   -I "$ROOT/include" -I "$ROOT/raytracer_amd/csrc" -x hip \
   "$ROOT/raytracer_amd/csrc/rt_kernels.hip" "$ROOT/raytracer_amd/csrc/rt_build_gpu.hip" \
-  "$ROOT/raytracer_amd/csrc/rt_api.cpp" "$ROOT/raytracer_amd/csrc/rt_bvh.cpp" "$ROOT/tools/sanitize/host_check.cpp" \
+  "$ROOT/raytracer_amd/csrc/rt_api.cpp" "$ROOT/raytracer_amd/csrc/rt_bvh.cpp" "$ROOT/tests/sanitize/host_check.cpp" \
   -x none "$OUT"/orc_*.o -lm -o "$OUT/host_check"
 ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 RT355_BUILD_THREADS=4 "$OUT/host_check"

@@ -13,6 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("mode", ["address", "thread"])
 def test_host_code_under_sanitizers(tmp_path, mode):
     env = dict(os.environ, TMPDIR=str(tmp_path))
-    out = subprocess.run([os.path.join(ROOT, "tools", "sanitize", "run.sh"), mode], env=env, capture_output=True,
+    out = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "run.sh"), mode], env=env, capture_output=True,
                          text=True, timeout=1500)
     assert out.returncode == 0 and "host_check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

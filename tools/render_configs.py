@@ -67,17 +67,8 @@ def main():
                "mean_rgb": [round(float(v), 5) for v in img[..., :3].mean((0, 1))],
                "finite": bool(np.isfinite(img).all())}
         if args.check:
-            from tests import orc
-            o = orc.OracleScene(fr, 4, args.split)
-            rng = np.random.default_rng(0)
-            opts = orc.render_opts(w, h, spp, depth, seed=0, **skw)
-            bad = 0
-            for pix in rng.integers(0, w * h, args.check):
-                rgb, _ = o.path_radiance(cam, opts, int(pix) * spp, spp)
-                acc = np.zeros(3, np.float32)
-                for s in range(spp):
-                    acc = acc + rgb[s]
-                bad += int(not (img[pix // w, pix % w, :3] == acc / np.float32(spp)).all())
+            from tests import spot_check  # the oracle stays behind tests/
+            bad = spot_check.pixels_different(fr, 4, args.split, cam, w, h, spp, depth, img, args.check, **skw)
             out["oracle_pixels_checked"] = args.check
             out["oracle_pixels_different"] = bad
         print(json.dumps(out), flush=True)
