@@ -1246,6 +1246,15 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             HIP_TRY(hipMemcpy(c, db->counters, sizeof c, hipMemcpyDeviceToHost));
             stats->nodes_visited = c[0];
             for (int k = 0; k < 8; k++) stats->prims_tested[k] = c[1 + k];
+#ifdef RT_TAIL_PROBE
+            {
+                unsigned long long tp[4];
+                HIP_TRY(hipMemcpy(tp, db->counters + 28, sizeof tp, hipMemcpyDeviceToHost));
+                if (tp[3])
+                    fprintf(stderr, "rt355 tail probe: loop launch %.3f ms, mean wave %.3f ms, %llu waves\n",
+                            (double)(tp[1] - ~tp[0]) / 1e5, (double)tp[2] / (double)tp[3] / 1e5, tp[3]);
+            }
+#endif
 #ifdef RT_PROFILE
             unsigned long long pr[12];
             HIP_TRY(hipMemcpy(pr, db->counters + 16, sizeof pr, hipMemcpyDeviceToHost));

@@ -87,7 +87,7 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
     float4 *base = lds_raw;
     if constexpr (LDSN) {
         const uint32_t n = S.n_pairs;
-        for (uint32_t i = threadIdx.x; i < 4 * n; i += kThreads) {
+        for (uint32_t i = threadIdx.x; i < 4 * n; i += blockDim.x) { // a launch may bring fewer threads
             float4 x = S.nodes[i]; // record i / 4, quarter i % 4
             base[(i & 3u) * n + (i >> 2)] = x;
         }
@@ -1705,6 +1705,9 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
     const uint32_t n_chunks = kShards * ((longest + 63) / 64);
     if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
+#ifdef RT_TAIL_PROBE
+    const unsigned long long probe_t0 = wall_clock64();
+#endif
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
     const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
@@ -1722,6 +1725,16 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   {0u, 0u}, 0u, 0u, 0u};
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
+#ifdef RT_TAIL_PROBE
+    // when do the waves of a launch finish?  (100 MHz clock; slots 28-31 of the counters)
+    if (COUNT && lane == 0) {
+        const unsigned long long t1 = wall_clock64();
+        atomicMax(&counters[28], ~probe_t0);
+        atomicMax(&counters[29], t1);
+        atomicAdd(&counters[30], t1 - probe_t0);
+        atomicAdd(&counters[31], 1ull);
+    }
+#endif
 }
 
 // Adds the batch's samples to the running per-pixel sums in sample order; the
