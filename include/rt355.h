@@ -13,6 +13,14 @@
  * All functions return RT_OK (0) or a negative error code and never throw or
  * abort across the boundary; rt_last_error() returns a thread-local message.
  * There is no CPU fallback: every compute entry point needs a HIP device.
+ *
+ * Threads: a scene may be used from several host threads at once, as the
+ * reference's BVH is Send + Sync.  The trace entry points run concurrently (give
+ * each caller its own stream for the device-pointer variants; callers sharing a
+ * stream are served in call order); rt_render*, rt_intersect_count and the first
+ * use of a device take a per-scene lock and run one at a time.  rt_scene_destroy
+ * must not overlap any other call on that scene.  Every entry point makes
+ * `device` the calling thread's current HIP device.
  */
 #ifndef RT355_H
 #define RT355_H

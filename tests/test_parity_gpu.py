@@ -309,3 +309,58 @@ def test_one_launch_kernel_with_film_sampler_and_shards(monkeypatch, scene_cache
         whole, _ = o.render(cam(w, h), orc.render_opts(w, h, spp, 30, seed=2))
         assert (parts[0][..., :3] + parts[1][..., :3] + parts[2][..., :3]).tobytes() == whole[..., :3].tobytes()
         g.close()
+
+
+def test_concurrent_callers(scene_cache):
+    """Host threads share one scene: four trace callers (two of them on the same stream) and
+    a renderer at once; every result equals the single-threaded oracle result."""
+    import threading
+    import torch
+    sd, cam, fr = scene_cache("week")
+    o = orc.OracleScene(fr)
+    g = lib.Scene(fr)
+    g.upload()
+    wb = o.world_bound()
+    lo, hi = np.maximum(wb[:3], -2000), np.minimum(wb[3:], 2000)
+    batches = [random_rays(20000 + 777 * k, lo, hi, 40 + k) for k in range(4)]
+    want_hits = [o.intersect(r) for r in batches]
+    want_occ = [o.occluded(r) for r in batches]
+    ropts = dict(width=64, height=32, spp=4, max_depth=8, seed=3)
+    want_img, _ = o.render(cam(64, 32), orc.render_opts(**ropts))
+    shared = torch.cuda.Stream()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), shared, shared]
+    d_rays = [torch.from_numpy(r.view(np.float32).reshape(-1, 8)).cuda() for r in batches]
+    d_hits = [torch.empty((len(r), 8), dtype=torch.float32, device="cuda") for r in batches]
+    d_occ = [torch.empty(len(r), dtype=torch.uint8, device="cuda") for r in batches]
+    torch.cuda.synchronize()
+    failures = []
+
+    def tracer(k):
+        try:
+            for _ in range(6):
+                d_hits[k].zero_()
+                d_occ[k].zero_()
+                torch.cuda.synchronize()
+                st = streams[k].cuda_stream
+                g.intersect_dev(d_rays[k].data_ptr(), len(batches[k]), d_hits[k].data_ptr(), st)
+                g.occluded_dev(d_rays[k].data_ptr(), len(batches[k]), d_occ[k].data_ptr(), st)
+                streams[k].synchronize()
+                assert_hits_equal(d_hits[k].cpu().numpy().view(abi.hit_dtype).reshape(-1), want_hits[k], "thread %d" % k)
+                assert (d_occ[k].cpu().numpy() == want_occ[k]).all()
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            failures.append((k, repr(e)))
+
+    def renderer():
+        try:
+            for _ in range(4):
+                img, _ = g.render(cam(64, 32), lib.render_opts(**ropts))
+                assert img.tobytes() == want_img.tobytes()
+        except BaseException as e:  # noqa: BLE001
+            failures.append(("render", repr(e)))
+
+    threads = [threading.Thread(target=tracer, args=(k,)) for k in range(4)] + [threading.Thread(target=renderer)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
