@@ -1148,6 +1148,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         loop_below = 0;
     }
     if (const char *e = getenv("RT355_LOOP_BELOW")) loop_below = strtoull(e, nullptr, 10);
+    // RT355_LOOP_STEAL=0: a wave of that launch reads its own sub-queue only (experiments)
+    const char *ls = getenv("RT355_LOOP_STEAL");
+    const bool loop_steal = !(ls && atoi(ls) == 0);
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
     EventList events; // destroyed on every way out
@@ -1192,7 +1195,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             if (rest)
                 HIP_TRY(rt::launch_bounce_loop(db->dev, db->shape, db->q[b & 1], db->counts, b, o->max_depth - 1,
                                                o->seed, db->radiance, db->bounce_scratch,
-                                               want_counters ? db->counters : nullptr, st));
+                                               want_counters ? db->counters : nullptr, st, loop_steal));
             else
                 HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
                                           db->counts, b, o->max_depth - 1, o->seed, db->radiance,
@@ -1250,9 +1253,28 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             {
                 unsigned long long tp[4];
                 HIP_TRY(hipMemcpy(tp, db->counters + 28, sizeof tp, hipMemcpyDeviceToHost));
-                if (tp[3])
+                if (tp[3]) {
                     fprintf(stderr, "rt355 tail probe: loop launch %.3f ms, mean wave %.3f ms, %llu waves\n",
                             (double)(tp[1] - ~tp[0]) / 1e5, (double)tp[2] / (double)tp[3] / 1e5, tp[3]);
+                    // per-wave records: start, queue read out, end (100 MHz), segments held then | turns after
+                    const uint32_t waves = rt::bounce_waves(db->shape);
+                    std::vector<unsigned long long> rec((size_t)waves * 5);
+                    HIP_TRY(hipMemcpy2D(rec.data(), 40, db->bounce_scratch, rt::kWaveLoopBytes, 40, waves,
+                                        hipMemcpyDeviceToHost));
+                    if (const char *f = getenv("RT355_TAIL_FILE")) {
+                        if (FILE *out = fopen(f, "w")) {
+                            const unsigned long long t0 = ~tp[0];
+                            for (uint32_t w = 0; w < waves; w++) {
+                                const unsigned long long *r = &rec[(size_t)w * 5];
+                                if (r[2] < t0 || r[2] > tp[1]) continue; // wave did not run in this launch
+                                fprintf(out, "%u %.4f %.4f %.4f %u %u %u %u\n", w, (double)(r[0] - t0) / 1e5,
+                                        r[1] ? (double)(r[1] - t0) / 1e5 : -1.0, (double)(r[2] - t0) / 1e5,
+                                        (unsigned)(r[3] >> 32), (unsigned)r[3], (unsigned)(r[4] >> 32), (unsigned)r[4]);
+                            }
+                            fclose(out);
+                        }
+                    }
+                }
             }
 #endif
 #ifdef RT_PROFILE

@@ -191,7 +191,32 @@ struct Blocks {
     // every mul-th block only, so that several counters share the claims of one array (one
     // address takes about 90 atomics per microsecond)
     uint32_t first = 0, mul = 1, add = 0;
+    // Sub-queues (bounce kernels that keep no out-queue): `base` is the offset of the current
+    // sub-queue's entries, and with `sizes` set a wave whose sub-queue is read out goes on with
+    // the next one's cursor (sizes[s * kCountStride], cursor right behind it, entries at s * cap),
+    // so that the sub-queues end together however unevenly the work fell on them.
+    uint32_t base = 0;
+    const uint32_t *sizes = nullptr;
+    uint32_t shard = 0, cap = 0, hops = 0;
     RT_DEV bool more() const { return blk < n; }
+    RT_DEV void claim() {
+        for (;;) {
+            uint32_t c = 0;
+            if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 1u);
+            blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
+            if (blk < n || !sizes || hops + 1 >= kShards) break;
+            hops++;
+            shard = (shard + 1) % kShards;
+            n = sizes[(size_t)shard * kCountStride];
+            cursor = const_cast<uint32_t *>(sizes) + (size_t)shard * kCountStride + 1;
+            base = shard * cap;
+        }
+        off = 0;
+    }
+    // a wave with no block of its own looks for one right away
+    RT_DEV void start() {
+        if (cursor && sizes && blk >= n) claim();
+    }
     // Hands the next unread entries to the lanes that want one, in lane order; kNone
     // for a lane that gets none (the current block is used up first, so some lanes
     // may have to ask again).
@@ -200,17 +225,15 @@ struct Blocks {
         const uint32_t len = blk < n ? min(64u, n - blk) : 0u;
         const uint32_t avail = len - off;
         const uint32_t rank = lane_rank(m);
-        const uint32_t idx = (want && rank < avail) ? blk + off + rank : kNone;
+        const uint32_t idx = (want && rank < avail) ? base + blk + off + rank : kNone;
         off += min((uint32_t)__popcll(m), avail);
         if (len != 0 && off >= len) {
             if (cursor) {
-                uint32_t c = 0;
-                if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 1u);
-                blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
+                claim();
             } else {
                 blk += stride;
+                off = 0;
             }
-            off = 0;
         }
         return idx;
     }
@@ -1500,6 +1523,10 @@ struct LoopFeed {
     uint32_t *save;
     uint32_t parked[2];
     uint32_t ring_head, ring_count, turns;
+#ifdef RT_TAIL_PROBE
+    unsigned long long probe_dry = 0; // clock when this wave first found the queue read out
+    uint32_t probe_held = 0, probe_turns_dry = 0, probe_batches = 0, probe_batch_fill = 0;
+#endif
 
     RT_DEV bool more() const { return ring_count != 0 || blocks.more(); }
 
@@ -1511,6 +1538,12 @@ struct LoopFeed {
         v3 beta = mk(0.0f, 0.0f, 0.0f);
         Rng rng{0, 0};
         uint32_t gpath = 0, local = kDead, depth = 0;
+#ifdef RT_TAIL_PROBE
+        if (probe_dry) {
+            probe_batches++;
+            probe_batch_fill += count;
+        }
+#endif
         if (lane < count) {
             const float4 *r = park + (size_t)(first + lane) * 5;
             const float4 p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3], p4 = r[4];
@@ -1576,6 +1609,15 @@ struct LoopFeed {
             ring_count = 0;
             blocks.blk = blocks.n;
         }
+#ifdef RT_TAIL_PROBE
+        if (!blocks.more()) {
+            if (!probe_dry) {
+                probe_dry = wall_clock64();
+                probe_held = ring_count + parked[0] + parked[1] + (uint32_t)__popcll(__ballot(L.has_ray));
+            }
+            probe_turns_dry++;
+        }
+#endif
         // park the finished segments, whole
         const bool finished = free && L.has_ray;
         const bool general = L.best != RT_MISS && (L.best & kBestRare) != 0;
@@ -1697,7 +1739,7 @@ struct LoopFeed {
 template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_bounce_loop(
     SceneDev S, Queue qin, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
-    uint8_t *scratch, unsigned long long *counters) {
+    uint8_t *scratch, unsigned long long *counters, uint32_t steal) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
     const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
@@ -1713,9 +1755,12 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
     const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
     uint8_t *mine = scratch + (size_t)w * kWaveLoopBytes;
-    LoopFeed feed{S, qin, (size_t)shard * qin.cap,
+    // the block claimer hands out entry numbers of the whole queue (it may move on to other
+    // sub-queues), so the feed's own offset is zero
+    LoopFeed feed{S, qin, 0,
                   Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
-                         counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
+                         counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u,
+                         shard * qin.cap, steal ? cin : nullptr, shard, qin.cap, 0u},
                   counts, shard, bounce, last, seed, radiance,
                   reinterpret_cast<float4 *>(mine),
                   reinterpret_cast<float4 *>(mine + kLoopParkBytes),
@@ -1723,12 +1768,20 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   reinterpret_cast<float4 *>(mine + kLoopParkBytes + kLoopLaneBytes),
                   reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
                   {0u, 0u}, 0u, 0u, 0u};
+    feed.blocks.start();
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
 #ifdef RT_TAIL_PROBE
     // when do the waves of a launch finish?  (100 MHz clock; slots 28-31 of the counters)
     if (COUNT && lane == 0) {
         const unsigned long long t1 = wall_clock64();
+        // per-wave record over the start of the wave's own memory (no longer in use)
+        unsigned long long *rec = reinterpret_cast<unsigned long long *>(mine);
+        rec[0] = probe_t0;
+        rec[1] = feed.probe_dry;
+        rec[2] = t1;
+        rec[3] = ((unsigned long long)feed.probe_held << 32) | feed.probe_turns_dry;
+        rec[4] = ((unsigned long long)feed.probe_batches << 32) | feed.probe_batch_fill;
         atomicMax(&counters[28], ~probe_t0);
         atomicMax(&counters[29], t1);
         atomicAdd(&counters[30], t1 - probe_t0);
@@ -1967,23 +2020,24 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
 
 hipError_t launch_bounce_loop(const SceneDev &S, const LaunchShape &L, const Queue &qin, uint32_t *counts,
                               uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance, uint8_t *scratch,
-                              unsigned long long *counters, hipStream_t stream) {
+                              unsigned long long *counters, hipStream_t stream, bool steal) {
+    const uint32_t st = steal ? 1u : 0u;
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) {
         if (counters)
             RT_LAUNCH((k_bounce_loop<true, true>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance, scratch,
-                      counters);
+                      counters, st);
         else
             RT_LAUNCH((k_bounce_loop<false, true>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
-                      scratch, counters);
+                      scratch, counters, st);
     } else {
         if (counters)
             RT_LAUNCH((k_bounce_loop<true, false>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
-                      scratch, counters);
+                      scratch, counters, st);
         else
             RT_LAUNCH((k_bounce_loop<false, false>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
-                      scratch, counters);
+                      scratch, counters, st);
     }
     return hipGetLastError();
 }

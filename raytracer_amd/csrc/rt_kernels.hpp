@@ -126,7 +126,7 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
 // later bounce where launch_bounce would have left its queue sizes.
 hipError_t launch_bounce_loop(const SceneDev &S, const LaunchShape &L, const Queue &qin, uint32_t *counts,
                               uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance, uint8_t *scratch,
-                              unsigned long long *counters, hipStream_t stream);
+                              unsigned long long *counters, hipStream_t stream, bool steal = true);
 // Film::new's table of filter values (film.rs:99-113), passed to the film kernel by value.
 struct FilterDev {
     float w[256];
