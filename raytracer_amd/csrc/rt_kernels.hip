@@ -201,9 +201,19 @@ struct Blocks {
     RT_DEV bool more() const { return blk < n; }
     RT_DEV void claim() {
         for (;;) {
-            uint32_t c = 0;
-            if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 1u);
-            blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
+            // moving from sub-queue to sub-queue, look before claiming: at the end of a launch
+            // every wave passes every cursor, and atomics on one address go one at a time
+            bool left = true;
+            if (sizes) {
+                const uint32_t seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                left = ((first + seen) * mul + add) * 64u < n;
+            }
+            blk = n;
+            if (left) {
+                uint32_t c = 0;
+                if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 1u);
+                blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
+            }
             if (blk < n || !sizes || hops + 1 >= kShards) break;
             hops++;
             shard = (shard + 1) % kShards;
