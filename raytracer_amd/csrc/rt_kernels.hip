@@ -197,14 +197,15 @@ struct Blocks {
     // so that the sub-queues end together however unevenly the work fell on them.
     uint32_t base = 0;
     const uint32_t *sizes = nullptr;
-    uint32_t shard = 0, cap = 0, hops = 0;
+    uint32_t shard = 0, cap = 0, hops = 0, looked = 0;
     RT_DEV bool more() const { return blk < n; }
     RT_DEV void claim() {
         for (;;) {
             // moving from sub-queue to sub-queue, look before claiming: at the end of a launch
             // every wave passes every cursor, and atomics on one address go one at a time
             bool left = true;
-            if (sizes) {
+            if (hops != looked) { // first claim on this sub-queue
+                looked = hops;
                 const uint32_t seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 left = ((first + seen) * mul + add) * 64u < n;
             }
