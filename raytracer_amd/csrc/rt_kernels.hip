@@ -197,28 +197,40 @@ struct Blocks {
     // so that the sub-queues end together however unevenly the work fell on them.
     uint32_t base = 0;
     const uint32_t *sizes = nullptr;
-    uint32_t shard = 0, cap = 0, hops = 0, looked = 0;
+    uint32_t shard = 0, cap = 0, hops = 0;
     RT_DEV bool more() const { return blk < n; }
+    static constexpr uint32_t kStealMin = 16; // blocks a sub-queue must have left to be taken from (mul 1, add 0)
     RT_DEV void claim() {
+        static_assert(kShards == 32, "one ballot word covers the sub-queues");
+        const uint32_t lane = threadIdx.x & 63;
         for (;;) {
-            // moving from sub-queue to sub-queue, look before claiming: at the end of a launch
-            // every wave passes every cursor, and atomics on one address go one at a time
-            bool left = true;
-            if (hops != looked) { // first claim on this sub-queue
-                looked = hops;
-                const uint32_t seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                left = ((first + seen) * mul + add) * 64u < n;
-            }
-            blk = n;
-            if (left) {
-                uint32_t c = 0;
-                if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 1u);
-                blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
-            }
-            if (blk < n || !sizes || hops + 1 >= kShards) break;
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(cursor, 1u);
+            blk = ((first + __builtin_amdgcn_readfirstlane(c)) * mul + add) * 64u;
+            if (blk < n || !sizes || hops >= 2 * kShards) break;
+            // This sub-queue is read out.  Lane s looks at sub-queue s (size and cursor), and the
+            // wave goes on with the next one that has blocks left: one round trip, not one per
+            // sub-queue, and no atomics on cursors that have nothing to give (at the end of a
+            // launch every wave comes by, and atomics on one address go one at a time).
             hops++;
-            shard = (shard + 1) % kShards;
-            n = sizes[(size_t)shard * kCountStride];
+            uint32_t size_s = 0, seen = 0;
+            if (lane < kShards) {
+                size_s = sizes[(size_t)lane * kCountStride];
+                seen = __hip_atomic_load(sizes + (size_t)lane * kCountStride + 1, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // only sub-queues with plenty left are worth the trip: when thousands of waves go for
+            // a sub-queue's last few blocks, nearly all of their atomics are for nothing
+            const int32_t blocks_left = (int32_t)((size_s + 63u) / 64u) - (int32_t)(first + seen);
+            const uint32_t left = (uint32_t)__ballot(lane < kShards && blocks_left >= (int32_t)kStealMin);
+            if (left == 0) {
+                blk = n;
+                break;
+            }
+            const uint32_t turn = (shard + 1) % kShards; // search from the neighbour on
+            const uint32_t rotated = turn ? (left >> turn) | (left << (kShards - turn)) : left;
+            shard = (turn + (uint32_t)__builtin_ctz(rotated)) % kShards;
+            n = (uint32_t)__builtin_amdgcn_readlane((int)size_s, (int)shard);
             cursor = const_cast<uint32_t *>(sizes) + (size_t)shard * kCountStride + 1;
             base = shard * cap;
         }
