@@ -311,6 +311,31 @@ def test_one_launch_kernel_with_film_sampler_and_shards(monkeypatch, scene_cache
         g.close()
 
 
+@pytest.mark.parametrize("nodes", ["lds", "global"])
+def test_one_launch_kernel_shares_sub_queues(monkeypatch, scene_cache, nodes):
+    """A frame with more blocks per sub-queue than waves, so that blocks are claimed and a wave
+    whose sub-queue is read out goes on with the others': same image and per-bounce segment
+    counts as the oracle and as one launch per bounce, with the sharing on and off."""
+    if nodes == "global":
+        monkeypatch.setenv("RT355_NODES", "global")
+    _, cam, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp, depth = 320, 200, 16, 50
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=9))
+    monkeypatch.setenv("RT355_LOOP_BELOW", "0")
+    base, bst = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=9))
+    monkeypatch.delenv("RT355_LOOP_BELOW")
+    assert base.tobytes() == ref.tobytes() and bst.segments == rst.segments
+    for loop_from in (0, 1, 3):
+        monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
+        for steal in ("1", "0"):
+            monkeypatch.setenv("RT355_LOOP_STEAL", steal)
+            img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=9))
+            assert st.trace_launches == loop_from + 1
+            assert img.tobytes() == ref.tobytes(), (loop_from, steal)
+            assert st.segments == rst.segments and list(st.bounce_rays) == list(bst.bounce_rays)
+
+
 def test_concurrent_callers(scene_cache):
     """Host threads share one scene: four trace callers (two of them on the same stream) and
     a renderer at once; every result equals the single-threaded oracle result."""
