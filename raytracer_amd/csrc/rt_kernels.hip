@@ -199,7 +199,10 @@ struct Blocks {
     const uint32_t *sizes = nullptr;
     uint32_t shard = 0, cap = 0, hops = 0;
     RT_DEV bool more() const { return blk < n; }
-    static constexpr uint32_t kStealMin = 16; // blocks a sub-queue must have left to be taken from (mul 1, add 0)
+#ifndef RT_STEAL_MIN
+#define RT_STEAL_MIN 256
+#endif
+    static constexpr uint32_t kStealMin = RT_STEAL_MIN; // blocks a sub-queue must have left to be taken from (mul 1, add 0)
     RT_DEV void claim() {
         static_assert(kShards == 32, "one ballot word covers the sub-queues");
         const uint32_t lane = threadIdx.x & 63;
@@ -219,8 +222,10 @@ struct Blocks {
                 seen = __hip_atomic_load(sizes + (size_t)lane * kCountStride + 1, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
             }
-            // only sub-queues with plenty left are worth the trip: when thousands of waves go for
-            // a sub-queue's last few blocks, nearly all of their atomics are for nothing
+            // only sub-queues with plenty left are worth the trip: paths started from a sub-queue's
+            // last few blocks by waves that were about to finish only make the launch end later
+            // (measured: threshold 16 costs a scene with even sub-queues 4 %, 256 nothing), and
+            // thousands of waves going for them spend their atomics for nothing
             const int32_t blocks_left = (int32_t)((size_s + 63u) / 64u) - (int32_t)(first + seen);
             const uint32_t left = (uint32_t)__ballot(lane < kShards && blocks_left >= (int32_t)kStealMin);
             if (left == 0) {
