@@ -40,6 +40,15 @@ RT_DEV uint32_t wave_index() {
     return __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 RT_DEV uint32_t wave_total() { return gridDim.x * (blockDim.x >> 6); }
+// Sub-queue of wave w.  Every kShards consecutive waves cover all sub-queues, and the cover
+// shifts by RT_SHARD_SHIFT from one group to the next, so that a sub-queue is served by waves
+// of every slot of a workgroup: a SIMD favours its oldest wave, and with plain w % kShards the
+// sub-queues of a workgroup's last-started waves were read out 30 % later than those of its
+// first (a wave only reads the blocks of its own sub-queue in the per-bounce kernel).
+#ifndef RT_SHARD_SHIFT
+#define RT_SHARD_SHIFT 4
+#endif
+RT_DEV uint32_t shard_of_wave(uint32_t w) { return (w + (uint32_t)RT_SHARD_SHIFT * (w / kShards)) % kShards; }
 
 // Two launch shapes.  Trees whose interior records fit beside the stacks are
 // copied into LDS by every workgroup (1024 threads, one per CU): incoherent rays
@@ -1495,7 +1504,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
-    const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
+    const uint32_t w = wave_index(), shard = shard_of_wave(w), per_shard = wave_total() / kShards;
     const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
     uint8_t *mine = scratch + (size_t)w * kWaveScratchBytes;
     BounceFeed feed{S, qin, qout, cout + shard * kCountStride, (size_t)shard * qin.cap, (size_t)shard * qout.cap,
@@ -1780,7 +1789,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 #endif
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
-    const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
+    const uint32_t w = wave_index(), shard = shard_of_wave(w), per_shard = wave_total() / kShards;
     const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
     uint8_t *mine = scratch + (size_t)w * kWaveLoopBytes;
     // the block claimer hands out entry numbers of the whole queue (it may move on to other
