@@ -13,9 +13,8 @@
 // from shard s appends its survivors to shard s of the next queue: one
 // ballot + prefix count + one atomic per wave, and the atomics of a launch
 // spread over kShards counters that sit on separate cache lines instead of
-// serialising on one word.  Because blocks are dealt round-robin to the 8
-// XCDs and the wave count is a multiple of kShards, every XCD keeps to its
-// own 4 shards from one bounce to the next.
+// serialising on one word.  The wave count is a multiple of kShards and
+// every kShards consecutive waves cover all sub-queues (shard_of_wave).
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 
@@ -1493,7 +1492,7 @@ struct BounceFeed {
 // survivors compacted into the next queue.  Radiance is stored once, when a
 // path ends on a light or leaves the scene.  The launch must have a wave count
 // that is a multiple of kShards, so that wave w reads and writes sub-queue
-// w % kShards only.
+// shard_of_wave(w) only.
 template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_bounce(
     SceneDev S, Queue qin, Queue qout, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
