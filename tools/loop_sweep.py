@@ -19,7 +19,7 @@ def t(o, n=4):
         s = g.render_dev(camf(w, h), o, fb.data_ptr(), st)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3, s
-for n in (8, 4, 2):
+for n in (1, 8, 4, 2):
     o = lib.render_opts(w, h, 64, 50, seed=0, shard=(0, n))
     os.environ.pop("RT355_LOOP_FROM", None); os.environ.pop("RT355_LOOP_BELOW", None)
     ms, s = t(o)
