@@ -356,6 +356,19 @@ int rt_intersect(rt_scene *scene, const rt_ray *rays, size_t n, rt_hit *hits, in
 int rt_intersect_dev(rt_scene *scene, const rt_ray *d_rays, size_t n, rt_hit *d_hits, int device,
                      void *stream);
 
+/* No counterpart in the reference.  rt_intersect_dev for callers that cannot allocate
+ * device memory: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Calls no hipMalloc / hipFree or any other allocating routine: the scene must
+ * already be resident on `device` (rt_scene_upload, else RT_ERR_INVALID), and the kernel's
+ * scratch -- the 2 KiB of block cursors its waves claim ray blocks from -- lives in a
+ * file-scope device array that each GPU holds for the life of the process.  At most
+ * RT_NOALLOC_MAX_RAYS rays per call (RT_ERR_LIMIT above).  Every call on a GPU shares that
+ * GPU's array: calls on one device must not overlap (same stream, or the caller orders
+ * them); overlapping calls race on the cursors and may skip or repeat ray blocks. */
+#define RT_NOALLOC_MAX_RAYS (1u << 28)
+int rt_intersect_dev_noalloc(rt_scene *scene, const rt_ray *d_rays, size_t n, rt_hit *d_hits, int device,
+                             void *stream);
+
 /* Traversal counters of one rt_intersect_dev launch: out[0] = nodes visited,
  * out[1 + kind] = primitives tested per kind (9 values). Synchronous. */
 int rt_intersect_count(rt_scene *scene, const rt_ray *d_rays, size_t n, rt_hit *d_hits, int device,

@@ -11,6 +11,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_DEPTH, RT_ERR_NOMEM, RT_ERR_LIMIT = (
     -1, -2, -3, -4, -5, -6)
 RT_MISS = 0xFFFFFFFF
+RT_NOALLOC_MAX_RAYS = 1 << 28
 
 # rt_prim_kind
 RT_SPHERE, RT_MOVING_SPHERE, RT_TRIANGLE, RT_RECT, RT_BOX, RT_GSPHERE, RT_MEDIUM = range(7)
@@ -133,7 +134,7 @@ ABI_SIZES = [
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_world_bound", "rt_scene_get_info",
     "rt_scene_get_nodes", "rt_scene_get_prim_order", "rt_scene_upload", "rt_intersect",
-    "rt_intersect_dev", "rt_intersect_count", "rt_occluded", "rt_occluded_dev",
+    "rt_intersect_dev", "rt_intersect_dev_noalloc", "rt_intersect_count", "rt_occluded", "rt_occluded_dev",
     "rt_generate_rays", "rt_render", "rt_render_dev", "rt_filter_table", "rt_sobol_tables", "rt_film_resolve_dev",
     "rt_last_error", "rt_abi_sizes",
 ]
@@ -161,6 +162,7 @@ def declare(lib, prefix="rt_"):
         fn("scene_upload", i32, vp, i32)
         fn("intersect", i32, vp, vp, sz, vp, i32)
         fn("intersect_dev", i32, vp, vp, sz, vp, i32, vp)
+        fn("intersect_dev_noalloc", i32, vp, vp, sz, vp, i32, vp)
         fn("intersect_count", i32, vp, vp, sz, vp, i32, P(u64 * 9))
         fn("occluded", i32, vp, vp, sz, vp, i32)
         fn("occluded_dev", i32, vp, vp, sz, vp, i32, vp)

@@ -128,7 +128,7 @@ struct rt_scene {
     float background[3] = {0, 0, 0};
     rt::BuiltTree tree;
     double build_ms = 0;
-    std::mutex lock;
+    mutable std::mutex lock;
     std::map<int, std::unique_ptr<DeviceBuffers>> devices;
 };
 
@@ -154,8 +154,16 @@ rt::GSphere derive_gsphere(const rt_gsphere &in) { // Sphere::new, shapes/src/sp
     return g;
 }
 
-bool validate(const rt_scene_desc *d) {
-    if (d->n_prims && !d->prims) return false;
+// 0, or what is wrong with the description
+const char *validate(const rt_scene_desc *d) {
+    if (d->n_prims && !d->prims) return "prims is null";
+    if (d->n_materials && !d->materials) return "materials is null";
+    if (d->n_textures && !d->textures) return "textures is null";
+    if (d->n_images && !d->images) return "images is null";
+    if (d->n_xforms && !d->xforms) return "xforms is null";
+    if (d->n_media && (!d->media || (!d->spheres && !d->boxes))) return "media or their boundaries are null";
+    for (uint32_t i = 0; i < d->n_images; i++)
+        if (!d->images[i].rgb8 || !d->images[i].w || !d->images[i].h) return "image without pixels";
     for (uint32_t i = 0; i < d->n_prims; i++) {
         const rt_prim_ref &p = d->prims[i];
         uint32_t kind = p.kind & 0xffu, lim = 0;
@@ -168,30 +176,34 @@ bool validate(const rt_scene_desc *d) {
         case RT_BOX: lim = d->n_boxes; table = d->boxes; break;
         case RT_GSPHERE: lim = d->n_gspheres; table = d->gspheres; break;
         case RT_MEDIUM: lim = d->n_media; table = d->media; break;
-        default: return false;
+        default: return "unknown primitive kind";
         }
-        if (p.index >= lim || !table) return false;
-        if (p.xform > d->n_xforms || p.xform > 0xffffu) return false;
-        if (d->n_materials && p.material >= d->n_materials) return false;
+        if (p.index >= lim || !table) return "primitive index out of range";
+        if (p.xform > d->n_xforms || p.xform > 0xffffu) return "primitive transform out of range";
+        if (d->n_materials && p.material >= d->n_materials) return "primitive material out of range";
+        if (kind == RT_RECT && d->rects[p.index].axis > 2) return "rectangle axis out of range";
         if (kind == RT_MEDIUM) {
             const rt_medium &m = d->media[p.index];
-            if (m.boundary_kind == RT_BOUNDARY_SPHERE ? m.boundary_index >= d->n_spheres
-                                                      : m.boundary_index >= d->n_boxes)
-                return false;
-            if (m.xform > d->n_xforms) return false;
+            if (m.boundary_kind == RT_BOUNDARY_SPHERE ? (m.boundary_index >= d->n_spheres || !d->spheres)
+                                                      : (m.boundary_index >= d->n_boxes || !d->boxes))
+                return "medium boundary out of range";
+            if (m.xform > d->n_xforms) return "medium transform out of range";
         }
     }
     for (uint32_t i = 0; i < d->n_materials; i++)
-        if (d->n_textures && d->materials[i].texture >= d->n_textures) return false;
+        if (d->n_textures && d->materials[i].texture >= d->n_textures) return "material texture out of range";
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const rt_texture &t = d->textures[i];
         if ((t.kind == RT_TEX_CHECKER || t.kind == RT_TEX_CHECKER_UV) &&
             (t.a >= d->n_textures || t.b >= d->n_textures))
-            return false;
-        if (t.kind == RT_TEX_IMAGE && t.a >= d->n_images) return false;
-        if (t.kind == RT_TEX_NOISE && (!d->perlin_vec || !d->perlin_perm)) return false;
+            return "checker texture refers to a texture out of range";
+        if (t.kind == RT_TEX_IMAGE && t.a >= d->n_images) return "texture image out of range";
+        if (t.kind == RT_TEX_NOISE && (!d->perlin_vec || !d->perlin_perm)) return "noise texture without Perlin tables";
     }
-    return true;
+    if (d->perlin_perm) // the kernels index perlin_vec[3 * (x ^ y ^ z)] with these
+        for (int i = 0; i < 768; i++)
+            if (d->perlin_perm[i] < 0 || d->perlin_perm[i] > 255) return "perlin_perm entry outside 0..255";
+    return nullptr;
 }
 
 Aabb prim_bounds(const rt_scene &s, const rt_prim_ref &pr) {
@@ -254,6 +266,7 @@ int upload(DeviceBuffers &db, const std::vector<T> &host, const T **dev) {
 void release(DeviceBuffers &db) {
     for (void *p : db.allocs) (void)hipFree(p);
     for (void *p : db.ws_allocs) (void)hipFree(p);
+    for (auto &kv : db.cursors) (void)hipFree(kv.second);
     db.allocs.clear();
     db.ws_allocs.clear();
     db.cursors.clear();
@@ -284,7 +297,6 @@ int with_cursor(DeviceBuffers &db, hipStream_t st, Launch launch) {
     if (!c) {
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, rt::kCursorBytes));
-        db.allocs.push_back(p);
         c = static_cast<uint32_t *>(p);
     }
     HIP_TRY(hipMemsetAsync(c, 0, rt::kCursorBytes, st));
@@ -292,16 +304,30 @@ int with_cursor(DeviceBuffers &db, hipStream_t st, Launch launch) {
     return RT_OK;
 }
 
-// 0, or the reason the sampler options are not accepted (Stratified::new / ZeroTwo::new arguments)
-const char *sampler_problem(const rt_render_opts &o) {
-    if (o.sampler > RT_SAMPLER_STRATIFIED) return "unknown sampler";
+// Forgets a stream that is about to be destroyed (its work must have completed): the map is
+// keyed by stream handle, and a caller that makes a stream per call would otherwise leave one
+// cursor behind per handle value it ever saw.
+void drop_cursor(DeviceBuffers &db, hipStream_t st) {
+    std::lock_guard<std::mutex> g(db.cursor_lock);
+    auto it = db.cursors.find(st);
+    if (it == db.cursors.end()) return;
+    (void)hipFree(it->second);
+    db.cursors.erase(it);
+}
+
+// RT_OK, or why the sampler options are not accepted (Stratified::new / ZeroTwo::new arguments)
+int sampler_check(const rt_render_opts &o) {
+    if (o.sampler > RT_SAMPLER_STRATIFIED) return fail(RT_ERR_INVALID, "unknown sampler");
+    if (o.sampler == RT_SAMPLER_SOBOL && std::max(o.width, o.height) > rt::kSobolMaxResolution)
+        return fail(RT_ERR_LIMIT, "the Sobol' sampler's tables end at a resolution of 2^26 (data/src/sobol.rs)");
     if (o.sampler == RT_SAMPLER_ZERO_TWO && (o.spp & (o.spp - 1)))
-        return "the (0,2) sampler needs a power-of-two spp (ZeroTwo::new rounds up: pass the rounded count)";
+        return fail(RT_ERR_INVALID,
+                    "the (0,2) sampler needs a power-of-two spp (ZeroTwo::new rounds up: pass the rounded count)");
     if (o.sampler == RT_SAMPLER_STRATIFIED) {
         const uint32_t nx = o.sampler_arg & 0xffffu;
-        if (!nx || o.spp % nx) return "stratified sampler: sampler_arg's x strata must divide spp";
+        if (!nx || o.spp % nx) return fail(RT_ERR_INVALID, "stratified sampler: sampler_arg's x strata must divide spp");
     }
-    return nullptr;
+    return RT_OK;
 }
 
 // Device memory the frame's camera sampler reads, filled on `stream`: the Sobol' tables, or
@@ -557,6 +583,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         db.shape.grid = std::max(8u, (uint32_t)prop.multiProcessorCount * per_cu / 8 * 8);
     }
     static_assert(rt::kShards == 32, "grid rounding above assumes 32 sub-queues");
+    HIP_TRY(rt::static_cursor_setup(device)); // for rt_intersect_dev_noalloc, which must not set anything up
     const size_t scratch_bytes = (size_t)rt::bounce_waves(db.shape) * std::max(rt::kWaveScratchBytes, rt::kWaveLoopBytes);
     HIP_TRY(hipMalloc(&p, scratch_bytes));
     db.allocs.push_back(p);
@@ -647,7 +674,7 @@ int rt_abi_sizes(uint32_t *out, size_t cap) {
 int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene **out) {
     if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (!validate(d)) return fail(RT_ERR_INVALID, "malformed scene description");
+    if (const char *why = validate(d)) return fail(RT_ERR_INVALID, "malformed scene description: %s", why);
     try {
         auto s = std::make_unique<rt_scene>();
         s->prims = copy_in(d->prims, d->n_prims);
@@ -673,7 +700,14 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
         for (const rt_gsphere &g : s->gspheres) s->gsph_derived.push_back(derive_gsphere(g));
         auto t0 = std::chrono::steady_clock::now();
         std::vector<Aabb> bounds(s->prims.size());
-        for (size_t i = 0; i < bounds.size(); i++) bounds[i] = prim_bounds(*s, s->prims[i]);
+        for (size_t i = 0; i < bounds.size(); i++) {
+            bounds[i] = prim_bounds(*s, s->prims[i]);
+            // NaN or infinite geometry would reach the builders' bucket and Morton casts
+            for (int k = 0; k < 3; k++)
+                if (!std::isfinite(bounds[i].lo[k]) || !std::isfinite(bounds[i].hi[k]) ||
+                    bounds[i].lo[k] > bounds[i].hi[k])
+                    return fail(RT_ERR_INVALID, "primitive %zu has no finite bounding box", i);
+        }
         std::string err;
         int rc;
         if (opts && (opts->flags & RT_BUILD_ON_DEVICE)) {
@@ -724,7 +758,10 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->n_nodes = (uint32_t)s->tree.nodes.size();
     out->max_depth = s->tree.max_depth;
     out->stack_slots = stack_slots(s);
-    for (auto &kv : s->devices) out->device_bytes = kv.second->bytes;
+    {
+        std::lock_guard<std::mutex> g(s->lock); // another thread may be adding a device
+        for (auto &kv : s->devices) out->device_bytes = kv.second->bytes;
+    }
     out->build_ms = s->build_ms;
     return RT_OK;
 }
@@ -761,6 +798,32 @@ int rt_intersect_dev(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits
              })) != RT_OK)
             return rc;
     }
+    return RT_OK;
+}
+
+// rt_intersect_dev for callers that must not allocate: the scene is already resident, the
+// block cursors live in a file-scope device array, one launch.
+int rt_intersect_dev_noalloc(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hits, int device, void *stream) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (n > RT_NOALLOC_MAX_RAYS)
+        return fail(RT_ERR_LIMIT, "rt_intersect_dev_noalloc takes at most %u rays per call (got %zu)",
+                    (unsigned)RT_NOALLOC_MAX_RAYS, n);
+    if (n && (!d_rays || !d_hits)) return fail(RT_ERR_INVALID, "null ray or hit buffer");
+    DeviceBuffers *db = nullptr;
+    {
+        std::lock_guard<std::mutex> g(s->lock);
+        auto it = s->devices.find(device);
+        if (it != s->devices.end()) db = it->second.get();
+    }
+    uint32_t *cursor = rt::static_cursor(device);
+    if (!db || !cursor)
+        return fail(RT_ERR_INVALID, "scene is not resident on device %d: call rt_scene_upload first "
+                                    "(rt_intersect_dev_noalloc allocates nothing)", device);
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(cursor, 0, rt::kCursorBytes, st));
+    HIP_TRY(rt::launch_intersect(db->dev, db->shape, d_rays, (uint32_t)n, d_hits, nullptr, cursor, st));
     return RT_OK;
 }
 
@@ -830,6 +893,8 @@ static int staged(rt_scene *s, const rt_ray *rays, size_t n, rt_hit *hits, uint8
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(RT_ERR_HIP, "kernel or download failed: %s", hipGetErrorString(e));
     }
+    (void)hipStreamSynchronize(st);
+    drop_cursor(*db, st);
     (void)hipFree(d_rays);
     (void)hipFree(d_out);
     (void)hipStreamDestroy(st);
@@ -854,7 +919,7 @@ int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t 
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
         return fail(RT_ERR_NO_DEVICE, "device %d not available; librt355 has no CPU path", device);
     if (n > kChunk) return fail(RT_ERR_LIMIT, "at most %zu rays per call", kChunk);
-    if (const char *why = sampler_problem(*opts)) return fail(RT_ERR_INVALID, "%s", why);
+    if (int bad = sampler_check(*opts)) return bad;
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(device));
     rt_ray *d = nullptr;
@@ -916,7 +981,8 @@ uint32_t sobol_setup(uint32_t width, uint32_t height, SobolDev &t) {
         for (uint32_t k = 0; k < 52; k++) t.m32[d][k] = (uint32_t)((mk[k] << (51 - k)) >> 20);
     }
     uint32_t m = 0;
-    while ((1u << m) < std::max(width, height)) m++; // round_up_pow_2 + log2usize, sobol.rs:15-21
+    const uint32_t res = std::min(std::max(width, height), kSobolMaxResolution); // callers reject larger frames
+    while ((1u << m) < res) m++; // round_up_pow_2 + log2usize, sobol.rs:15-21
     if (m == 0) return 0;
     auto T = [&](uint32_t j) {
         return ((uint64_t)(t.m32[0][j] >> (32 - m)) << m) | (uint64_t)(t.m32[1][j] >> (32 - m));
@@ -1062,6 +1128,8 @@ int rt_filter_table(const rt_filter *f, float out[256]) {
 
 int rt_sobol_tables(uint32_t width, uint32_t height, uint32_t m32[260], uint64_t vdc[52], uint64_t inv[52]) {
     if (!m32 || !vdc || !inv || !width || !height) return fail(RT_ERR_INVALID, "bad argument");
+    if (std::max(width, height) > rt::kSobolMaxResolution)
+        return fail(RT_ERR_LIMIT, "the Sobol' tables end at a resolution of 2^26 (data/src/sobol.rs)");
     rt::SobolDev t;
     (void)rt::sobol_setup(width, height, t);
     memcpy(m32, t.m32, sizeof t.m32);
@@ -1103,7 +1171,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     }
     std::lock_guard<std::mutex> g(db->render_lock);
 
-    if (const char *why = sampler_problem(*o)) return fail(RT_ERR_INVALID, "%s", why);
+    if (int bad = sampler_check(*o)) return bad;
     rt::FrameDev F{};
     F.width = o->width;
     F.height = o->height;
@@ -1151,6 +1219,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     // RT355_LOOP_STEAL=0: a wave of that launch reads its own sub-queue only (experiments)
     const char *ls = getenv("RT355_LOOP_STEAL");
     const bool loop_steal = !(ls && atoi(ls) == 0);
+    // RT355_LOOP_TURN_LIMIT=<turns>: test hook for the spin guard of that launch
+    uint32_t turn_limit = rt::kLoopTurnLimit;
+    if (const char *e = getenv("RT355_LOOP_TURN_LIMIT")) turn_limit = (uint32_t)strtoul(e, nullptr, 10);
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
     EventList events; // destroyed on every way out
@@ -1195,7 +1266,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             if (rest)
                 HIP_TRY(rt::launch_bounce_loop(db->dev, db->shape, db->q[b & 1], db->counts, b, o->max_depth - 1,
                                                o->seed, db->radiance, db->bounce_scratch,
-                                               want_counters ? db->counters : nullptr, st, loop_steal));
+                                               want_counters ? db->counters : nullptr, st, loop_steal, turn_limit));
             else
                 HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
                                           db->counts, b, o->max_depth - 1, o->seed, db->radiance,
@@ -1216,6 +1287,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, counts.size() * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (counts[rt::kLoopErrorWord])
+            return fail(RT_ERR_LIMIT, "a wave of the path kernel exceeded %u feed turns and dropped its segments: "
+                                      "the frame is incomplete", turn_limit);
         const uint64_t live = (uint64_t)owned_pixels * sc; // entries of bounce 0 that are not padding
         paths += live;
         for (uint32_t b = 0; b < o->max_depth; b++) {

@@ -15,6 +15,8 @@
 // spread over kShards counters that sit on separate cache lines instead of
 // serialising on one word.  The wave count is a multiple of kShards and
 // every kShards consecutive waves cover all sub-queues (shard_of_wave).
+#include <mutex>
+
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 
@@ -1563,7 +1565,7 @@ struct LoopFeed {
     float4 *ring;   // [slot][4]: a, b, c as in Queue, d = lane_d
     uint32_t *save;
     uint32_t parked[2];
-    uint32_t ring_head, ring_count, turns;
+    uint32_t ring_head, ring_count, turns, turn_limit;
 #ifdef RT_TAIL_PROBE
     unsigned long long probe_dry = 0; // clock when this wave first found the queue read out
     uint32_t probe_held = 0, probe_turns_dry = 0, probe_batches = 0, probe_batch_fill = 0;
@@ -1646,9 +1648,13 @@ struct LoopFeed {
     RT_DEV bool turn(Trav &T, bool free) {
         Lane &L = T.L;
         const uint32_t lane = threadIdx.x & 63;
-        if (++turns > (1u << 24)) { // cannot happen; keeps a wave from spinning forever if it did
+        if (++turns > turn_limit) {
+            // No frame comes near the limit; it only keeps a wave from spinning forever.  The wave
+            // drops what it holds, so the frame is incomplete: say so where the host looks after
+            // every batch (it then fails the call instead of returning a wrong image).
             ring_count = 0;
             blocks.blk = blocks.n;
+            if (lane == 0) atomicOr(&counts[kLoopErrorWord], 1u);
         }
 #ifdef RT_TAIL_PROBE
         if (!blocks.more()) {
@@ -1780,7 +1786,7 @@ struct LoopFeed {
 template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_bounce_loop(
     SceneDev S, Queue qin, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
-    uint8_t *scratch, unsigned long long *counters, uint32_t steal) {
+    uint8_t *scratch, unsigned long long *counters, uint32_t steal, uint32_t turn_limit) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
     const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
@@ -1808,7 +1814,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   reinterpret_cast<uint4 *>(mine + kLoopParkBytes + 64 * 16),
                   reinterpret_cast<float4 *>(mine + kLoopParkBytes + kLoopLaneBytes),
                   reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
-                  {0u, 0u}, 0u, 0u, 0u};
+                  {0u, 0u}, 0u, 0u, 0u, turn_limit};
     feed.blocks.start();
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
@@ -1986,6 +1992,39 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
     return hipGetLastError();
 }
 
+// ---- block cursors of the entry point that allocates nothing ------------------------------------------
+// The trace kernels claim their ray blocks from kShards counters (one per 64-byte line) that are
+// zero at launch.  The ordinary entry points keep one such block per caller stream in memory
+// from hipMalloc; rt_intersect_dev_noalloc uses this file-scope array instead.  Every device
+// that loads the library holds its own copy at its own address, which host code must ask the
+// runtime for: the name below is only a stand-in on the host side.
+static __device__ __align__(256) uint32_t scratch[kShards * kCountStride];
+static_assert(sizeof(scratch) == kCursorBytes, "one cursor block");
+
+namespace {
+constexpr int kMaxDevices = 64;
+uint32_t *g_scratch_ptr[kMaxDevices]; // address of `scratch` on device d, or null before static_cursor_setup(d)
+std::mutex g_scratch_lock;
+} // namespace
+
+// Once per device, with that device current (the scene upload does it).
+hipError_t static_cursor_setup(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(g_scratch_lock);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = static_cast<uint32_t *>(p);
+    return hipSuccess;
+}
+
+uint32_t *static_cursor(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> g(g_scratch_lock);
+    return g_scratch_ptr[device];
+}
+
 hipError_t launch_pixel_samples(const FrameDev &F, uint32_t n_slots, bool by_rank, uint64_t first_pixel, float *out,
                                 hipStream_t stream) {
     if (!n_slots) return hipSuccess;
@@ -2061,24 +2100,24 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
 
 hipError_t launch_bounce_loop(const SceneDev &S, const LaunchShape &L, const Queue &qin, uint32_t *counts,
                               uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance, uint8_t *scratch,
-                              unsigned long long *counters, hipStream_t stream, bool steal) {
+                              unsigned long long *counters, hipStream_t stream, bool steal, uint32_t turn_limit) {
     const uint32_t st = steal ? 1u : 0u;
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) {
         if (counters)
             RT_LAUNCH((k_bounce_loop<true, true>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance, scratch,
-                      counters, st);
+                      counters, st, turn_limit);
         else
             RT_LAUNCH((k_bounce_loop<false, true>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
-                      scratch, counters, st);
+                      scratch, counters, st, turn_limit);
     } else {
         if (counters)
             RT_LAUNCH((k_bounce_loop<true, false>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
-                      scratch, counters, st);
+                      scratch, counters, st, turn_limit);
         else
             RT_LAUNCH((k_bounce_loop<false, false>), L.grid, threads, S, qin, counts, bounce, last, seed, radiance,
-                      scratch, counters, st);
+                      scratch, counters, st, turn_limit);
     }
     return hipGetLastError();
 }

@@ -66,6 +66,8 @@ struct FrameDev {
     const float *pixel_samples;
 };
 
+// MATRICES / MATRICES_INV of data/src/sobol.rs have 26 rows: resolutions up to 2^26.
+constexpr uint32_t kSobolMaxResolution = 1u << 26;
 // Fills `h` for a width x height frame (host).
 void halton_setup(uint32_t width, uint32_t height, HaltonDev &h);
 // Fills `t` for a width x height frame (host); returns m = log2 of the resolution.
@@ -98,6 +100,11 @@ size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds);
 // which the waves claim their ray blocks), or null for a static deal of the blocks
 hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n,
                             rt_hit *hits, unsigned long long *counters, uint32_t *cursor, hipStream_t stream);
+// The cursor block that lives in a file-scope device array instead of allocated memory (one per
+// device, shared by every caller on that device).  static_cursor_setup asks the runtime for its
+// address on `device`, which must be current; static_cursor returns it, or null before that.
+hipError_t static_cursor_setup(int device);
+uint32_t *static_cursor(int device);
 hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray *rays, uint32_t n, uint8_t *out,
                            uint32_t *cursor, hipStream_t stream);
 // pixel samplers: F.pixel_samples holds the pixels first / spp ... (slot = pixel - first / spp)
@@ -124,9 +131,15 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
 // Bounce `bounce` and all later ones of the paths queued in qin (sizes at
 // counts[(bounce * kShards + s) * kCountStride]); writes the number of segments traced at each
 // later bounce where launch_bounce would have left its queue sizes.
+// A wave that takes more than turn_limit feed turns gives up, drops the segments it holds and
+// sets counts[kLoopErrorWord] (a word of the counter block no kernel uses otherwise; cleared
+// with the block): the frame is then incomplete and the caller must fail it.
+constexpr uint32_t kLoopErrorWord = 2;
+constexpr uint32_t kLoopTurnLimit = 1u << 24;
 hipError_t launch_bounce_loop(const SceneDev &S, const LaunchShape &L, const Queue &qin, uint32_t *counts,
                               uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance, uint8_t *scratch,
-                              unsigned long long *counters, hipStream_t stream, bool steal = true);
+                              unsigned long long *counters, hipStream_t stream, bool steal = true,
+                              uint32_t turn_limit = kLoopTurnLimit);
 // Film::new's table of filter values (film.rs:99-113), passed to the film kernel by value.
 struct FilterDev {
     float w[256];

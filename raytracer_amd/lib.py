@@ -149,6 +149,10 @@ class Scene:
     def intersect_dev(self, rays_ptr, n, hits_ptr, stream=None):
         check(self._lib.rt_intersect_dev(self._h, rays_ptr, n, hits_ptr, self.device, stream))
 
+    def intersect_dev_noalloc(self, rays_ptr, n, hits_ptr, stream=None):
+        """rt_intersect_dev without any device allocation (the scene must be uploaded)."""
+        check(self._lib.rt_intersect_dev_noalloc(self._h, rays_ptr, n, hits_ptr, self.device, stream))
+
     def occluded_dev(self, rays_ptr, n, out_ptr, stream=None):
         check(self._lib.rt_occluded_dev(self._h, rays_ptr, n, out_ptr, self.device, stream))
 

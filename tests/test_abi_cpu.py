@@ -107,6 +107,95 @@ def test_errors_are_codes_not_aborts():
     L.rt_scene_destroy(None)  # no-op
 
 
+def _one_sphere(noise=False):
+    s = SceneData()
+    if noise:
+        s.set_perlin()
+        s.lambertian(texture=s.add_texture(abi.RT_TEX_NOISE, scale=0.1))
+    else:
+        s.lambertian((1, 1, 1))
+    s.add_sphere((0, 0, 0), 1.0)
+    s.add_rect(1, 0.0, -1.0, 1.0, -1.0, 1.0)
+    return s.freeze()
+
+
+def test_descriptions_with_dangling_tables_or_bad_values_are_rejected():
+    """Counts without tables, Perlin permutation entries the kernels would index out of
+    bounds with, non-finite geometry and a rectangle axis above 2 all come back as
+    RT_ERR_INVALID with a reason."""
+    L = lib.load()
+    h = C.c_void_p()
+    opts = abi.rt_build_opts(4, 0)
+
+    def create(fr):
+        rc = L.rt_scene_create(C.byref(fr.desc), C.byref(opts), C.byref(h))
+        return rc, L.rt_last_error().decode()
+
+    fr = _one_sphere()
+    assert create(fr)[0] == abi.RT_OK
+    L.rt_scene_destroy(h)
+    for field, word in (("materials", "materials is null"), ("textures", "textures is null"),
+                        ("prims", "prims is null")):
+        fr = _one_sphere()
+        setattr(fr.desc, field, None)
+        rc, msg = create(fr)
+        assert rc == abi.RT_ERR_INVALID and word in msg, (field, msg)
+    fr = _one_sphere()
+    fr.desc.n_images = 1  # count without a table
+    rc, msg = create(fr)
+    assert rc == abi.RT_ERR_INVALID and "images is null" in msg
+    for bad in (-1, 256, 1 << 20):
+        fr = _one_sphere(noise=True)
+        fr._keep["perlin"][1][2, 17] = bad
+        rc, msg = create(fr)
+        assert rc == abi.RT_ERR_INVALID and "perlin_perm" in msg, (bad, msg)
+    for value in (np.nan, np.inf, -np.inf):
+        fr = _one_sphere()
+        fr._keep["spheres"]["c"][0, 1] = value
+        rc, msg = create(fr)
+        assert rc == abi.RT_ERR_INVALID and "finite" in msg, (value, msg)
+    fr = _one_sphere()
+    fr._keep["spheres"]["r"][0] = np.nan
+    assert create(fr)[0] == abi.RT_ERR_INVALID
+    fr = _one_sphere()
+    fr._keep["rects"]["axis"][0] = 3
+    rc, msg = create(fr)
+    assert rc == abi.RT_ERR_INVALID and "axis" in msg
+
+
+def test_sobol_tables_stop_at_the_reference_tables_last_row():
+    """data/src/sobol.rs holds MATRICES / MATRICES_INV for resolutions up to 2^26: larger
+    frames are RT_ERR_LIMIT, not an overrun of the 52-column tables."""
+    assert lib.sobol_tables(1 << 26, 3)[1].shape == (52,)
+    for w, h in (((1 << 26) + 1, 1), (5, 1 << 27), (0xFFFFFFFF, 0xFFFFFFFF), (0x80000001, 2)):
+        with pytest.raises(lib.RtError) as e:
+            lib.sobol_tables(w, h)
+        assert e.value.code == abi.RT_ERR_LIMIT
+    # the same bound guards the entry points that take a sampler (checked before any device use)
+    import torch
+    if not torch.cuda.is_available():
+        cam = abi.rt_camera()
+        opts = lib.render_opts((1 << 26) + 1, 1, 1, sampler=abi.RT_SAMPLER_SOBOL)
+        rays = np.zeros(1, dtype=abi.ray_dtype)
+        rc = lib.load().rt_generate_rays(C.byref(cam), C.byref(opts), 0, 1, rays.ctypes.data, 0)
+        assert rc in (abi.RT_ERR_LIMIT, abi.RT_ERR_NO_DEVICE)
+
+
+def test_no_alloc_entry_point_argument_errors():
+    """rt_intersect_dev_noalloc never uploads (that would allocate): a scene that is not
+    resident, a batch above the fixed maximum and null buffers are errors."""
+    L = lib.load()
+    g = lib.Scene(_one_sphere())
+    assert L.rt_intersect_dev_noalloc(None, None, 0, None, 0, None) == abi.RT_ERR_INVALID
+    rc = L.rt_intersect_dev_noalloc(g._h, 16, abi.RT_NOALLOC_MAX_RAYS + 1, 16, 0, None)
+    assert rc == abi.RT_ERR_LIMIT and b"at most" in L.rt_last_error()
+    assert L.rt_intersect_dev_noalloc(g._h, None, 4, None, 0, None) == abi.RT_ERR_INVALID
+    rc = L.rt_intersect_dev_noalloc(g._h, 16, 4, 16, 0, None)  # never uploaded
+    assert rc == abi.RT_ERR_INVALID and b"rt_scene_upload" in L.rt_last_error()
+    header = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    assert "#define RT_NOALLOC_MAX_RAYS (1u << 28)" in header and abi.RT_NOALLOC_MAX_RAYS == 1 << 28
+
+
 def test_deep_tree_is_rejected_like_the_reference_stack():
     # centroids spaced geometrically make the middle split peel one primitive per level:
     # the tree needs more than the 64 stack entries of bvh.rs:753

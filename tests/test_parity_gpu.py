@@ -336,6 +336,24 @@ def test_one_launch_kernel_shares_sub_queues(monkeypatch, scene_cache, nodes):
             assert st.segments == rst.segments and list(st.bounce_rays) == list(bst.bounce_rays)
 
 
+def test_spin_guard_of_the_one_launch_kernel_is_reported(monkeypatch, scene_cache):
+    """A wave of the kernel that follows paths to their end gives up after a fixed number of
+    feed turns and drops its segments; the call must then fail instead of returning the
+    incomplete frame.  Forced here with a limit of three turns."""
+    _, cam, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp = 96, 64, 4
+    monkeypatch.setenv("RT355_LOOP_FROM", "1")
+    monkeypatch.setenv("RT355_LOOP_TURN_LIMIT", "3")
+    with pytest.raises(lib.RtError) as e:
+        g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=4))
+    assert e.value.code == abi.RT_ERR_LIMIT and "incomplete" in str(e.value)
+    monkeypatch.delenv("RT355_LOOP_TURN_LIMIT")
+    img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=4))  # the scene is still usable
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, 50, seed=4))
+    assert img.tobytes() == ref.tobytes() and st.segments == rst.segments
+
+
 def test_concurrent_callers(scene_cache):
     """Host threads share one scene: four trace callers (two of them on the same stream) and
     a renderer at once; every result equals the single-threaded oracle result."""
