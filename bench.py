@@ -20,9 +20,18 @@ Extra objects on the JSON line:
                   counters of an untimed counting frame; identical to the oracle's)
                   over the summed duration of the frame's bounce launches, measured
                   with HIP events recorded on the launch stream inside the timed
-                  steps.
+                  steps.  On this scene the tree is read from LDS, so those bytes never
+                  reach HBM and the kernel's real limit is vector-instruction issue:
+                  `bound` says so, and `traffic` (HBM bytes per launch) and `valu`
+                  (instructions per segment, issue rate against the chip's, active
+                  lanes) carry the hardware counters of a separate rocprofv3 run --
+                  only when that run was made with the kernel sources of this tree
+                  (a hash of them is stored with the counters), null otherwise.
   cpu_baseline -- the CPU oracle (a port of the reference algorithm, not the
-                  product) timed on the host cores on a bounded sample.
+                  product) built -O3 -march=native -ffp-contract=off on the machine
+                  and timed on its host cores on a bounded sample, before the GPU
+                  phase.
+  host         -- CPU model, core count and the threads the CPU leg used.
 """
 import argparse
 import ctypes as C
@@ -48,9 +57,49 @@ def algorithmic_bytes(stats):
     return int(b)
 
 
+def kernel_source_hash():
+    """Identifies the kernels a counter file was measured on (there is no git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for name in ("rt_kernels.hip", "rt_kernels.hpp", "rt_device.hpp", "rt_api.cpp"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+
+
+def native_oracle():
+    """Builds the oracle for this machine (-O3 -march=native) into a temporary directory and makes
+    tests/orc.py load it; the portable in-tree build is the fallback.  Returns the flags used."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="orc_native_"), "liborc_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "NATIVE_OUT=" + out,
+                               "liborc_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["ORC_LIB"] = out
+        return "gcc -O3 -march=native -ffp-contract=off"
+    except (OSError, subprocess.CalledProcessError):
+        return "gcc -O3 -ffp-contract=off (portable build; native build failed)"
+
+
 def cpu_baseline(frozen, cam, threads, target_s=15.0):
     """Oracle (port of the reference path) on the host cores, bounded sample:
     the same 1920x1080 frame at fewer samples per pixel."""
+    flags = native_oracle()
     from tests import orc
     o = orc.OracleScene(frozen)
     t0 = time.time()
@@ -61,8 +110,8 @@ def cpu_baseline(frozen, cam, threads, target_s=15.0):
     _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, spp, DEPTH, seed=0), threads=threads)
     dt = time.time() - t0
     return {"value": round(st.segments / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads,
-            "kind": "port", "sample": "week scene %dx%d, %d of %d spp, depth %d (%.1f s)" % (
-                WIDTH, HEIGHT, spp, SPP, DEPTH, dt)}
+            "kind": "port", "build": flags,
+            "sample": "week scene %dx%d, %d of %d spp, depth %d (%.1f s)" % (WIDTH, HEIGHT, spp, SPP, DEPTH, dt)}
 
 
 def main():
@@ -103,6 +152,11 @@ def main():
     sd, camf = scenes.next_week()
     frozen = sd.freeze()
     cam = camf(WIDTH, HEIGHT)
+    # CPU leg first (rank 0 of a single-GPU run only): the GPU phase then runs in one piece
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+        cpu = cpu_baseline(frozen, cam, threads)
     scene = lib.Scene(frozen, 4, abi.RT_SPLIT_SAH, device=local_rank)
     scene.upload()
     info = scene.info()
@@ -167,22 +221,43 @@ def main():
                                                            info.n_nodes),
                        "sharding": "32x32 tiles round-robin over ranks, one reduce(sum) per frame",
                        "ray_segments_per_frame": int(segments / args.steps)},
-            "roofline": {"kernel": "k_bounce + k_bounce_loop", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "k_bounce + k_bounce_loop",
+                         # the interior records of this tree are staged in LDS by every workgroup: the
+                         # algorithmic bytes are served by LDS, and the counters show vector-instruction
+                         # issue, not memory, as the limit (valu, below)
+                         "bound": "valu", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes / max(launches_per_frame, 1)),
                          "avg_launch_ms": round(per_launch_ms, 4),
                          "launches_per_frame": launches_per_frame,
-                         "note": "tree and primitive tables are LDS / L2 resident; bytes are algorithmic"},
+                         "valu": None,
+                         "note": "achieved/peak/frac: algorithmic bytes (32 B per node visited + ray, result and "
+                                 "primitive records) over the HBM peak, as the metric is defined; the tree is "
+                                 "LDS resident, so this is not HBM traffic (see traffic) and the limit is "
+                                 "instruction issue (see valu)"},
+            "host": host_info(),
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(traffic_file):  # measured on whole-frame launches
-            with open(traffic_file) as f:
-                out["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
-        if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(
-                16, len(os.sched_getaffinity(0)))
-            out["cpu_baseline"] = cpu_baseline(frozen, cam, threads)
+        # hardware counters of a rocprofv3 run on these very kernel sources (tools/collect_pmc.sh)
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_current.json")
+        if world == 1 and os.path.exists(pmc_file):
+            with open(pmc_file) as f:
+                pmc = json.load(f)
+            if pmc.get("source_hash") == kernel_source_hash() and pmc.get("spp") == args.spp:
+                out["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")
+                v = pmc.get("valu")
+                if v:
+                    seg = float(pmc.get("segments_per_frame", segments / args.steps))
+                    rate = v["wave_insts_per_frame"] / (trace_ms / args.steps * 1e-3)
+                    out["roofline"]["valu"] = {
+                        "wave_insts_per_segment": round(v["wave_insts_per_frame"] / seg, 2),
+                        "achieved_ginst_s": round(rate / 1e9, 1), "peak_ginst_s": v["peak_ginst_s"],
+                        "frac": round(rate / 1e9 / v["peak_ginst_s"], 4),
+                        "active_lane_frac": v.get("active_lane_frac"), "peak_basis": v.get("peak_basis"),
+                        "source": pmc.get("source", "profiles/pmc_current.json")}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["host"]["cpu_threads_used"] = cpu["cores"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

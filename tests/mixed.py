@@ -7,7 +7,7 @@ from raytracer_amd import abi
 from raytracer_amd.scene import SceneData, rotate, rotate_y, translate
 
 
-def mixed_scene(seed=1, n_each=40, with_normals=True):
+def mixed_scene(seed=1, n_each=40, with_normals=True, with_media=True):
     rng = np.random.default_rng(seed)
     s = SceneData(background=(0.5, 0.6, 0.8))
     s.set_perlin()
@@ -61,6 +61,8 @@ def mixed_scene(seed=1, n_each=40, with_normals=True):
         z = None if i % 2 == 0 else (-0.6 * r, 0.8 * r)
         phi = 360.0 if i % 4 < 2 else 200.0
         s.add_gsphere(m, r, z=z, phi_max=phi, material=mat(), reverse=bool(i % 5 == 0))
+    if not with_media:
+        return s
     s.add_medium(0.4, iso, sphere=(pos(), 3.0))
     s.add_medium(0.2, iso, box=((-2.0, -2.0, -2.0), (2.0, 3.0, 2.5)),
                  xform=s.add_xform(translate((4.0, 0.0, -3.0)) @ rotate_y(30.0)))

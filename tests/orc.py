@@ -18,9 +18,10 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ORACLE_DIR, "liborc.so")
+        # ORC_LIB: another build of the same sources (bench.py's -march=native one)
+        path = os.environ.get("ORC_LIB") or os.path.join(ORACLE_DIR, "liborc.so")
         if not os.path.exists(path):
-            subprocess.check_call(["make", "-C", ORACLE_DIR, "liborc.so"])
+            subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.basename(path)])
         L = C.CDLL(path)
         abi.declare(L, prefix="orc_")
         vp, sz, i32, u64, P = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER

@@ -1,0 +1,76 @@
+"""The oracle against an independent float64 intersector (tests/fp64_ref.py, written from the
+shapes' geometry): hit / miss and primitive index equal on every ray that is not grazing, hit
+distance within 1e-5 relative, geometric normal and surface (u, v) within the stated absolute
+bounds -- for every surface kind: spheres (also negative radius), moving spheres at random
+times, triangles with vertex normals and uvs, rectangles and boxes with and without instance
+transforms and reverse flags, and the reference's transformed, z- and phi-clipped spheres."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+from raytracer_amd.scene import SceneData, rotate, translate
+from tests import fp64_ref, orc
+from tests.conftest import random_rays
+from tests.mixed import mixed_scene
+
+# fp32 results against float64: t relative, normal components and (u, v) absolute
+TOL = dict(rel_t=1e-5, abs_n=1e-5, abs_uv=2e-5)
+
+
+def clipped_spheres_scene(seed=3, n=24):
+    """Only the reference's Sphere (sphere.rs:28-47): rotation + translation (+ a handedness
+    swap), z clipping, phi clipping, reverse_orientation, in every combination."""
+    rng = np.random.default_rng(seed)
+    s = SceneData()
+    s.lambertian((1, 1, 1))
+    for i in range(n):
+        r = float(rng.random() * 2.0 + 0.8)
+        m = translate((rng.random(3) - 0.5) * 16) @ rotate(rng.random(3) + 0.1, float(rng.random() * 360))
+        if i % 3 == 1:
+            m = m @ np.diag([1.0, 1.0, -1.0, 1.0])
+        z = None if i % 4 == 0 else (float(-r * rng.random()), float(r * rng.random()))
+        phi = [360.0, 270.0, 135.0][i % 3] if i % 2 else 360.0
+        s.add_gsphere(m, r, z=z, phi_max=phi, reverse=bool(i % 5 == 2))
+    return s
+
+
+def check_against_fp64(intersect, frozen, rays, min_clear=0.85, min_hits=1000):
+    f64 = fp64_ref.Fp64Scene(frozen)
+    best = f64.closest(rays)
+    clear = fp64_ref.clear_rays(f64, rays, best)
+    assert clear.mean() > min_clear, clear.mean()
+    out = fp64_ref.compare(intersect(rays), best, clear, **TOL)
+    assert out["n_hits"] >= min_hits, out
+    return out, best, clear
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_oracle_matches_fp64_on_every_surface_kind(seed):
+    fr = mixed_scene(seed=seed, n_each=40, with_media=False).freeze()
+    o = orc.OracleScene(fr)
+    rays = random_rays(8000, (-12, -12, -12), (12, 12, 12), 50 + seed, finite_fraction=0.2, axis_fraction=0.0)
+    out, best, clear = check_against_fp64(o.intersect, fr, rays)
+    kinds = set(np.unique(fr._keep["prims"]["kind"][best["prim"][clear & (best["prim"] >= 0)]] & 0xFF))
+    assert kinds == {abi.RT_SPHERE, abi.RT_MOVING_SPHERE, abi.RT_TRIANGLE, abi.RT_RECT, abi.RT_BOX,
+                     abi.RT_GSPHERE}, kinds
+
+
+def test_oracle_matches_fp64_on_clipped_transformed_spheres():
+    fr = clipped_spheres_scene().freeze()
+    o = orc.OracleScene(fr)
+    rays = random_rays(12000, (-9, -9, -9), (9, 9, 9), 8, finite_fraction=0.1, axis_fraction=0.0)
+    out, best, clear = check_against_fp64(o.intersect, fr, rays, min_hits=1500)
+    # rays that enter through a cut-away part and hit the inside of the far wall are among them
+    f64 = fp64_ref.Fp64Scene(fr)
+    assert ((best["n"] * rays["d"]).sum(1)[clear & (best["prim"] >= 0)] > 0).mean() > 0.05
+    assert f64.skipped_media == 0
+
+
+def test_any_hit_agrees_with_fp64_closest_hit():
+    fr = mixed_scene(seed=3, n_each=40, with_media=False).freeze()
+    o = orc.OracleScene(fr)
+    rays = random_rays(6000, (-12, -12, -12), (12, 12, 12), 4, finite_fraction=0.3, axis_fraction=0.0)
+    f64 = fp64_ref.Fp64Scene(fr)
+    best = f64.closest(rays)
+    clear = fp64_ref.clear_rays(f64, rays, best)
+    assert ((o.occluded(rays) != 0) == (best["prim"] >= 0))[clear].all()

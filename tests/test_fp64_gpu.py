@@ -1,0 +1,60 @@
+"""The HIP path's output against the independent float64 intersector (tests/fp64_ref.py),
+through the C ABI and without the oracle anywhere in the comparison: hit / miss and primitive
+index equal on every ray that is not grazing, t within 1e-5 relative, geometric normals and
+(u, v) within the bounds stated in tests/fp64_ref.py -- on seeded scenes holding every surface
+kind, on the reference's clipped, transformed spheres, and on camera and random rays of the
+four named benchmark scenes (rays whose closest hit is a medium are left out: a medium's hit
+distance is a hash of the ray)."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, lib
+from tests import fp64_ref
+from tests.conftest import random_rays
+from tests.mixed import mixed_scene
+from tests.test_fp64_cpu import TOL, check_against_fp64, clipped_spheres_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hip_matches_fp64_on_every_surface_kind(seed):
+    fr = mixed_scene(seed=seed, n_each=40, with_media=False).freeze()
+    g = lib.Scene(fr)
+    rays = random_rays(20000, (-12, -12, -12), (12, 12, 12), 70 + seed, finite_fraction=0.2, axis_fraction=0.0)
+    out, best, clear = check_against_fp64(g.intersect, fr, rays, min_hits=3000)
+    kinds = set(np.unique(fr._keep["prims"]["kind"][best["prim"][clear & (best["prim"] >= 0)]] & 0xFF))
+    assert kinds == set(range(6)), kinds
+    # any-hit agrees with the float64 closest hit on the same rays
+    assert ((g.does_intersect(rays) != 0) == (best["prim"] >= 0))[clear].all()
+
+
+@pytest.mark.parametrize("nodes", ["lds", "global"])
+def test_hip_matches_fp64_on_clipped_transformed_spheres(monkeypatch, nodes):
+    if nodes == "global":
+        monkeypatch.setenv("RT355_NODES", "global")
+    fr = clipped_spheres_scene().freeze()
+    g = lib.Scene(fr)
+    rays = random_rays(30000, (-9, -9, -9), (9, 9, 9), 8, finite_fraction=0.1, axis_fraction=0.0)
+    check_against_fp64(g.intersect, fr, rays, min_hits=4000)
+
+
+@pytest.mark.parametrize("name", ["random", "cornell", "week", "pbrt"])
+def test_hip_matches_fp64_on_the_benchmark_scenes(scene_cache, name):
+    from tests import orc  # ray generation only (camera rays as plain data); not part of the comparison
+    sd, cam, fr = scene_cache(name)
+    g = lib.Scene(fr)
+    wb = g.world_bound()
+    lo, hi = np.maximum(wb[:3], -1500), np.minimum(wb[3:], 1500)
+    prim = lib.generate_rays(cam(128, 64), lib.render_opts(128, 64, 1), 0, 128 * 64)
+    rays = np.concatenate([prim, random_rays(6000, lo, hi, 5, finite_fraction=0.1, axis_fraction=0.0)])
+    hits = g.intersect(rays)
+    kinds = fr._keep["prims"]["kind"] & 0xFF
+    medium_hit = (hits["prim"] != abi.RT_MISS) & (kinds[np.minimum(hits["prim"], len(kinds) - 1)] == abi.RT_MEDIUM)
+    keep = ~medium_hit
+    f64 = fp64_ref.Fp64Scene(fr)
+    best = f64.closest(rays[keep])
+    clear = fp64_ref.clear_rays(f64, rays[keep], best, eps_o=1e-6 * float(np.abs(hi - lo).max()))
+    assert clear.mean() > 0.8, clear.mean()
+    out = fp64_ref.compare(hits[keep], best, clear, **TOL)
+    assert out["n_hits"] > 2000, out
