@@ -17,8 +17,9 @@ same conditioning (it only bounds the error, float.rs:182-204, and re-projects t
 the sphere, sphere.rs:72).  So each sphere hit carries its kappa and the bound it is checked
 against is  1e-5 + 16 eps kappa  (eps = 2^-23; measured worst case 5.3 eps kappa); hits with
 kappa < 32 are additionally held to the plain 1e-5.  The bound on t also carries the
-resolution of the ray's own fp32 coordinates, 8 eps max|o| / |d| (an origin 0.005 in front of a
-plane at coordinate 14 cannot know t to 1e-5 relative).
+resolution of the ray's own fp32 coordinates, 2 eps max|o| / |d| (an origin 0.005 in front of a
+plane at coordinate 14 cannot know t to 1e-5 relative), divided by the cosine of incidence
+and taken in object space for a transformed primitive.
 
 Conventions (the reference's, shapes/src/sphere.rs:110-136, triangle.rs:204-345):
   sphere         z-polar: phi = atan2(y, x) in [0, 2 pi), u = phi / phi_max,
@@ -70,6 +71,7 @@ class Fp64Scene:
         self.k = k
         self.prims = k["prims"]
         self.skipped_media = int((self.prims["kind"] & 0xFF == abi.RT_MEDIUM).sum())
+        self._object_coord = None  # largest object-space coordinate of the primitive just tested
 
     def closest(self, rays, prim_mask=None):
         """-> dict(t, prim, n, u, v) ; prim = -1 for a miss.  rays: abi.ray_dtype array."""
@@ -85,8 +87,8 @@ class Fp64Scene:
                     u=np.zeros(n), v=np.zeros(n), kappa=np.ones(n), radius=np.zeros(n),
                     t_second=np.full(n, np.inf))
         dlen = np.linalg.norm(D, axis=1)
-        # what fp32 coordinates of this size can resolve along the ray
-        best["t_resolution"] = EPS * np.abs(O).max(axis=1) / dlen
+        best["t_resolution"] = np.zeros(n)
+        world_coord = np.abs(O).max(axis=1)
         k = self.k
         with np.errstate(all="ignore"):
             for pid, pr in enumerate(self.prims):
@@ -123,6 +125,12 @@ class Fp64Scene:
                     kappa = np.maximum(1.0, dist_sq / (radius * radius * np.maximum(cos_i, 1e-12)))
                 else:
                     kappa, radius = 1.0, 0.0
+                # what fp32 coordinates of this size can resolve along the ray: eps * coordinate /
+                # (|d| cos(incidence)); in object space for a transformed primitive
+                coord = np.maximum(world_coord, self._object_coord) if self._object_coord is not None else world_coord
+                cos_any = np.maximum(np.abs((nrm * D).sum(1)) / (dlen * np.linalg.norm(nrm, axis=1)), 1e-3)
+                best["t_resolution"] = np.where(ok, EPS * coord / (dlen * cos_any), best["t_resolution"])
+                self._object_coord = None
                 best["kappa"] = np.where(ok, kappa, best["kappa"])
                 best["radius"] = np.where(ok, radius, best["radius"])
                 best["t"] = np.where(ok, t, best["t"])
@@ -188,7 +196,9 @@ class Fp64Scene:
             return O, D, None
         x = self.k["xforms"][xf - 1]
         w2o = _m34(x["w2o"])
-        return _apply_point(w2o, O), _apply_vector(w2o, D), w2o
+        o = _apply_point(w2o, O)
+        self._object_coord = np.abs(O) @ np.abs(w2o[:, :3]).T.max(axis=1) + np.abs(w2o[:, 3]).max()
+        return o, _apply_vector(w2o, D), w2o
 
     def _rect(self, O, D, r, xf, reverse):
         o, d, w2o = self._object_ray(O, D, xf)
@@ -318,7 +328,7 @@ def compare(hits, best, clear, rel_t=1e-5, abs_n=1e-5, abs_uv=1e-5, kappa_factor
     du = np.minimum(du, np.abs(1.0 - du))  # phi = 0 and phi = 2 pi are the same meridian
     dv = np.abs(hits["v"][h].astype(np.float64) - best["v"][h])
     duv = np.maximum(du, dv)
-    t_bound = rel_t * best["t"][h] + 8 * best["t_resolution"][h] + slack * best["radius"][h]
+    t_bound = rel_t * best["t"][h] + 2 * best["t_resolution"][h] + slack * best["radius"][h]
     out = dict(n_hits=int(h.sum()), t=float((dt / t_bound).max()), n=float((dn / (abs_n + slack)).max()),
                uv=float((duv / (abs_uv + slack)).max()))
     assert out["t"] <= 1.0 and out["n"] <= 1.0 and out["uv"] <= 1.0, out
