@@ -233,6 +233,9 @@ typedef struct rt_scene_info {
     uint32_t stack_slots; /* stack entries a lane of the kernels can need (max_depth - 1) */
     uint64_t device_bytes;
     double build_ms;
+    uint32_t n_enclosing; /* media enclosing the scene, kept out of the tree (see rt_scene_create) */
+    uint32_t enclosing[4]; /* their primitive indices, ascending                                  */
+    uint32_t _pad;
 } rt_scene_info;
 
 /* Perspective camera: colour/src/camera/perspective.rs:16-78 with
@@ -327,21 +330,29 @@ typedef struct rt_scene rt_scene;
  * (bvh.rs:661-691).  Nothing is uploaded until a device is first used.
  * With RT_BUILD_ON_DEVICE (split method HLBVH) the Morton codes, the radix sort
  * and the treelets of hlbvh_build (bvh.rs:385-538) are computed on opts->device;
- * the tree is the same, node for node. */
+ * the tree is the same, node for node.
+ * Media that enclose the scene (a Volume whose sphere contains the box around every
+ * primitive that is not a sphere-bounded medium, e.g. the fog of test/week.toml:86-93) are
+ * not given to the tree: every ray would meet them.  Up to four of them, in primitive order,
+ * are tested once per ray before its traversal, and a hit shortens the ray like any other;
+ * rt_scene_info lists them.  The reference has no media; its tree is built over exactly the
+ * primitives it knows. */
 int rt_scene_create(const rt_scene_desc *desc, const rt_build_opts *opts, rt_scene **out);
 
 /* Drop for BVH. Frees host and device memory on every device used. */
 void rt_scene_destroy(rt_scene *scene);
 
-/* Primitive::world_bound (bvh.rs:728-734): root bounds {lo.xyz, hi.xyz}; an
- * empty scene gives the inverted box Bounds3::ZERO (bounds3.rs:23-26). */
+/* Primitive::world_bound (bvh.rs:728-734): root bounds {lo.xyz, hi.xyz} (joined with
+ * the bounds of the enclosing media, which are part of the scene); an empty scene gives
+ * the inverted box Bounds3::ZERO (bounds3.rs:23-26). */
 int rt_scene_world_bound(const rt_scene *scene, float out[6]);
 
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
 
 /* The flattened tree in the reference's own node format (bvh.rs:79-101) and
  * the primitive order the leaves index (BVH::primitives after construct,
- * bvh.rs:146).  `cap` = capacity of `out` in elements; returns the count. */
+ * bvh.rs:146).  `cap` = capacity of `out` in elements; returns the count (the
+ * primitives of the tree: n_prims - n_enclosing). */
 int64_t rt_scene_get_nodes(const rt_scene *scene, rt_linear_node *out, size_t cap);
 int64_t rt_scene_get_prim_order(const rt_scene *scene, uint32_t *out, size_t cap);
 

@@ -133,14 +133,15 @@ void orc_scene_destroy(orc_scene *s) {
 
 int orc_scene_world_bound(const orc_scene *s, float out[6]) { /* bvh.rs:728-734 */
     if (!s || !out) return RT_ERR_INVALID;
+    aabb b = aabb_empty();
     if (s->n_nodes) {
-        memcpy(out, s->nodes[0].lo, 12);
-        memcpy(out + 3, s->nodes[0].hi, 12);
-    } else {
-        aabb e = aabb_empty();
-        out[0] = e.lo.x; out[1] = e.lo.y; out[2] = e.lo.z;
-        out[3] = e.hi.x; out[4] = e.hi.y; out[5] = e.hi.z;
+        b.lo = v3_make(s->nodes[0].lo[0], s->nodes[0].lo[1], s->nodes[0].lo[2]);
+        b.hi = v3_make(s->nodes[0].hi[0], s->nodes[0].hi[1], s->nodes[0].hi[2]);
     }
+    for (uint32_t e = 0; e < s->n_enclosing; e++) /* the media kept out of the tree belong to the scene */
+        b = aabb_union(b, orc_prim_bounds(s, s->enclosing[e]));
+    out[0] = b.lo.x; out[1] = b.lo.y; out[2] = b.lo.z;
+    out[3] = b.hi.x; out[4] = b.hi.y; out[5] = b.hi.z;
     return RT_OK;
 }
 
@@ -152,6 +153,8 @@ int orc_scene_get_info(const orc_scene *s, rt_scene_info *out) {
     out->max_depth = s->max_depth;
     out->stack_slots = 64;
     out->build_ms = s->build_ms;
+    out->n_enclosing = s->n_enclosing;
+    for (uint32_t k = 0; k < s->n_enclosing; k++) out->enclosing[k] = s->enclosing[k];
     return RT_OK;
 }
 
@@ -163,13 +166,13 @@ int64_t orc_scene_get_nodes(const orc_scene *s, rt_linear_node *out, size_t cap)
 }
 int64_t orc_scene_get_prim_order(const orc_scene *s, uint32_t *out, size_t cap) {
     if (!s) return RT_ERR_INVALID;
-    size_t n = s->n_prims < cap ? s->n_prims : cap;
+    size_t n = s->n_tree_prims < cap ? s->n_tree_prims : cap;
     if (out && n && s->order) memcpy(out, s->order, n * sizeof *out);
-    return (int64_t)s->n_prims;
+    return (int64_t)s->n_tree_prims;
 }
 int orc_scene_set_tree(orc_scene *s, const rt_linear_node *nodes, size_t n_nodes,
                        const uint32_t *order, size_t n_prims) {
-    if (!s || n_prims != s->n_prims) return RT_ERR_INVALID;
+    if (!s || n_prims != s->n_tree_prims) return RT_ERR_INVALID;
     free(s->nodes);
     free(s->order);
     s->nodes = dup_mem(nodes, n_nodes * sizeof *nodes);

@@ -257,7 +257,7 @@ static bnode *emit_lbvh(builder *B, const pinfo *by_prim, const morton_prim *mp,
         leaf->first = B->n_ordered;
         leaf->count = n;
         for (uint32_t i = 0; i < n; i++) {
-            B->ordered[B->n_ordered++] = mp[i].prim_index;
+            B->ordered[B->n_ordered++] = by_prim[mp[i].prim_index].prim;
             b = aabb_union(b, by_prim[mp[i].prim_index].b);
         }
         leaf->b = b;
@@ -357,7 +357,7 @@ static bnode *hlbvh_build(builder *B, uint32_t n) { /* bvh.rs:385-449 */
         float ox = offset_dim(cb, B->info[i].c, 0) * 1024.0f;
         float oy = offset_dim(cb, B->info[i].c, 1) * 1024.0f;
         float oz = offset_dim(cb, B->info[i].c, 2) * 1024.0f;
-        mp[i].prim_index = B->info[i].prim;
+        mp[i].prim_index = i; /* place in info; the primitive's number is info[i].prim */
         mp[i].code = morton3(ox, oy, oz);
     }
     radix_sort(mp, tmp, n);
@@ -420,13 +420,55 @@ uint32_t orc_tree_depth(const rt_linear_node *nodes, uint32_t n_nodes) {
     return best + 1;
 }
 
+/* Media that enclose the scene.  The scene files put a thin fog around everything
+ * (test/week.toml:86-93: a Volume whose boundary is a sphere of radius 5000 about the origin).
+ * As a primitive of the tree such a medium is a child of the root that every ray meets, and it
+ * stretches the root box to its own size.  Rule, the same in the library: a medium bounded by a
+ * sphere encloses the scene when the box around all primitives that are not sphere-bounded
+ * media lies strictly inside its sphere (all eight corners, distances in double precision).
+ * The first ORC_MAX_ENCLOSING such media in primitive order are left out of the tree and tested
+ * once per ray before the traversal starts, in that order; a hit shortens the ray like any
+ * other.  The reference has no media at all, so nothing of it is re-ordered by this. */
+static void find_enclosing(orc_scene *s, const aabb *bounds) {
+    s->n_enclosing = 0;
+    aabb others = aabb_empty();
+    int any = 0;
+    for (uint32_t i = 0; i < s->n_prims; i++) {
+        const rt_prim_ref *p = &s->prims[i];
+        if ((p->kind & 0xffu) == RT_MEDIUM && s->media[p->index].boundary_kind == RT_BOUNDARY_SPHERE) continue;
+        others = aabb_union(others, bounds[i]);
+        any = 1;
+    }
+    if (!any) return;
+    for (uint32_t i = 0; i < s->n_prims && s->n_enclosing < ORC_MAX_ENCLOSING; i++) {
+        const rt_prim_ref *p = &s->prims[i];
+        if ((p->kind & 0xffu) != RT_MEDIUM || s->media[p->index].boundary_kind != RT_BOUNDARY_SPHERE) continue;
+        const rt_sphere *sp = &s->spheres[s->media[p->index].boundary_index];
+        int inside = 1;
+        for (int c = 0; c < 8 && inside; c++) {
+            double dx = (double)((c & 1) ? others.hi.x : others.lo.x) - (double)sp->c[0];
+            double dy = (double)((c & 2) ? others.hi.y : others.lo.y) - (double)sp->c[1];
+            double dz = (double)((c & 4) ? others.hi.z : others.lo.z) - (double)sp->c[2];
+            inside = dx * dx + dy * dy + dz * dz < (double)sp->r * (double)sp->r;
+        }
+        if (inside) s->enclosing[s->n_enclosing++] = i;
+    }
+}
+
 int orc_build(orc_scene *s, const rt_build_opts *opts) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    uint32_t n = s->n_prims;
     s->n_nodes = 0;
     s->max_depth = 0;
-    if (n == 0) return RT_OK;
+    s->n_enclosing = 0;
+    s->n_tree_prims = s->n_prims;
+    if (s->n_prims == 0) return RT_OK;
+    aabb *bounds = (aabb *)malloc((size_t)s->n_prims * sizeof *bounds);
+    if (!bounds) { orc_set_error("out of memory building tree"); return RT_ERR_NOMEM; }
+    for (uint32_t i = 0; i < s->n_prims; i++) bounds[i] = orc_prim_bounds(s, i);
+    find_enclosing(s, bounds);
+    s->n_tree_prims = s->n_prims - s->n_enclosing;
+    uint32_t n = s->n_tree_prims;
     builder B;
     memset(&B, 0, sizeof B);
     B.s = s;
@@ -438,15 +480,18 @@ int orc_build(orc_scene *s, const rt_build_opts *opts) {
     B.pool_cap = 2 * n + 1;
     B.pool = (bnode *)malloc((size_t)B.pool_cap * sizeof *B.pool);
     if (!B.info || !B.ordered || !B.pool) {
-        free(B.info); free(B.ordered); free(B.pool);
+        free(B.info); free(B.ordered); free(B.pool); free(bounds);
         orc_set_error("out of memory building tree");
         return RT_ERR_NOMEM;
     }
-    for (uint32_t i = 0; i < n; i++) { /* BVHPrimitiveInfo::new, bvh.rs:694-703 */
-        B.info[i].prim = i;
-        B.info[i].b = orc_prim_bounds(s, i);
-        B.info[i].c = v3_add(v3_scale(B.info[i].b.lo, 0.5f), v3_scale(B.info[i].b.hi, 0.5f));
+    for (uint32_t i = 0, k = 0, e = 0; i < s->n_prims; i++) { /* BVHPrimitiveInfo::new, bvh.rs:694-703 */
+        if (e < s->n_enclosing && s->enclosing[e] == i) { e++; continue; }
+        B.info[k].prim = i;
+        B.info[k].b = bounds[i];
+        B.info[k].c = v3_add(v3_scale(B.info[k].b.lo, 0.5f), v3_scale(B.info[k].b.hi, 0.5f));
+        k++;
     }
+    free(bounds);
     bnode *root = (B.method == RT_SPLIT_HLBVH) ? hlbvh_build(&B, n) : recursive_build(&B, 0, n);
     int rc = RT_OK;
     if (!root || B.n_ordered != n) {
@@ -503,7 +548,6 @@ int orc_slab(const rt_linear_node *n, const rt_ray *ray, const float inv[3], con
  * never shortens the ray (its Primitive::intersect returns no distance); here
  * t_max shrinks on every accepted hit, ties go to the later primitive. */
 int orc_closest(const orc_scene *s, const rt_ray *ray_in, orc_surf *out, uint64_t counters[9]) {
-    if (s->n_nodes == 0) return 0;
     rt_ray ray = *ray_in;
     float inv[3] = {1.0f / ray.d[0], 1.0f / ray.d[1], 1.0f / ray.d[2]};
     int neg[3] = {inv[0] < 0.0f, inv[1] < 0.0f, inv[2] < 0.0f};
@@ -512,7 +556,17 @@ int orc_closest(const orc_scene *s, const rt_ray *ray_in, orc_surf *out, uint64_
     int found = 0;
     uint32_t best_prim = 0;
     float best_aux[4] = {0, 0, 0, 0};
-    for (;;) {
+    for (uint32_t e = 0; e < s->n_enclosing; e++) { /* media around the whole scene: see find_enclosing */
+        float t, aux[4] = {0, 0, 0, 0};
+        if (counters) counters[1 + RT_MEDIUM]++;
+        if (orc_prim_test(s, s->enclosing[e], &ray, &t, aux)) {
+            ray.t_max = t;
+            found = 1;
+            best_prim = s->enclosing[e];
+            memcpy(best_aux, aux, sizeof aux);
+        }
+    }
+    for (; s->n_nodes != 0;) {
         const rt_linear_node *node = &s->nodes[cur];
         if (counters) counters[0]++;
         if (orc_slab(node, &ray, inv, neg)) {
@@ -548,6 +602,10 @@ int orc_closest(const orc_scene *s, const rt_ray *ray_in, orc_surf *out, uint64_
 
 /* any hit, bvh.rs:801-863 */
 int orc_any(const orc_scene *s, const rt_ray *ray) {
+    for (uint32_t e = 0; e < s->n_enclosing; e++) {
+        float t, aux[4];
+        if (orc_prim_test(s, s->enclosing[e], ray, &t, aux)) return 1;
+    }
     if (s->n_nodes == 0) return 0;
     float inv[3] = {1.0f / ray->d[0], 1.0f / ray->d[1], 1.0f / ray->d[2]};
     int neg[3] = {inv[0] < 0.0f, inv[1] < 0.0f, inv[2] < 0.0f};

@@ -7,6 +7,8 @@
 
 typedef struct { v3 lo, hi; } aabb;
 
+#define ORC_MAX_ENCLOSING 4
+
 /* Bounds3::ZERO is the inverted box [+MAX, -MAX], geometry/src/bounds3.rs:23-26 */
 static inline aabb aabb_empty(void) {
     aabb b = {{3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f},
@@ -58,10 +60,14 @@ struct orc_scene {
     float *perlin_vec;
     int32_t *perlin_perm;
     float background[3];
-    /* tree */
+    /* Media that enclose the scene are kept out of the tree (see orc_build): every ray meets
+     * them, so they are tested once per ray, before the traversal, in this order. */
+    uint32_t n_enclosing, enclosing[ORC_MAX_ENCLOSING];
+    uint32_t n_tree_prims; /* n_prims - n_enclosing */
+    /* tree over the other primitives */
     rt_linear_node *nodes;
     uint32_t n_nodes;
-    uint32_t *order; /* ordered primitive ids (leaf ranges index this) */
+    uint32_t *order; /* ordered primitive ids (leaf ranges index this), n_tree_prims entries */
     uint32_t max_depth;
     double build_ms;
 };

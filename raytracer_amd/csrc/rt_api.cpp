@@ -126,6 +126,9 @@ struct rt_scene {
     std::vector<float> perlin_vec;
     std::vector<int32_t> perlin_perm;
     float background[3] = {0, 0, 0};
+    // media that enclose the scene: kept out of the tree, tested once per ray before the
+    // traversal (find_enclosing); caller's primitive indices in ascending order
+    std::vector<uint32_t> enclosing;
     rt::BuiltTree tree;
     double build_ms = 0;
     mutable std::mutex lock;
@@ -248,6 +251,44 @@ Aabb prim_bounds(const rt_scene &s, const rt_prim_ref &pr) {
         return m.xform ? xf_box(s.xforms[m.xform - 1].o2w, b) : b;
     }
     }
+}
+
+// Media that enclose the scene.  The scene files put a thin fog around everything
+// (test/week.toml:86-93: a Volume bounded by a sphere of radius 5000 about the origin).  As a
+// primitive of the tree such a medium is a child of the root that every ray meets, tested
+// inside the most divergent code of the kernels, and it stretches the root box to its own
+// size.  A medium bounded by a sphere encloses the scene when the box around all primitives
+// that are not sphere-bounded media lies strictly inside its sphere (all eight corners,
+// distances in double precision).  The first kMaxEnclosing such media in primitive order are
+// left out of the tree; every ray tests them once before its traversal starts, in that order,
+// and a hit shortens the ray like any other.  The reference has no media, so this re-orders
+// nothing of it.
+std::vector<uint32_t> find_enclosing(const rt_scene &s, const std::vector<Aabb> &bounds) {
+    std::vector<uint32_t> out;
+    auto sphere_medium = [&](const rt_prim_ref &p) {
+        return (p.kind & 0xffu) == RT_MEDIUM && s.media[p.index].boundary_kind == RT_BOUNDARY_SPHERE;
+    };
+    Aabb others = rt::empty_box();
+    bool any = false;
+    for (size_t i = 0; i < s.prims.size(); i++) {
+        if (sphere_medium(s.prims[i])) continue;
+        others = join(others, bounds[i]);
+        any = true;
+    }
+    if (!any) return out;
+    for (size_t i = 0; i < s.prims.size() && out.size() < rt::kMaxEnclosing; i++) {
+        if (!sphere_medium(s.prims[i])) continue;
+        const rt_sphere &sp = s.spheres[s.media[s.prims[i].index].boundary_index];
+        bool inside = true;
+        for (int c = 0; c < 8 && inside; c++) {
+            const double dx = (double)((c & 1) ? others.hi[0] : others.lo[0]) - (double)sp.c[0];
+            const double dy = (double)((c & 2) ? others.hi[1] : others.lo[1]) - (double)sp.c[1];
+            const double dz = (double)((c & 4) ? others.hi[2] : others.lo[2]) - (double)sp.c[2];
+            inside = dx * dx + dy * dy + dz * dz < (double)sp.r * (double)sp.r;
+        }
+        if (inside) out.push_back((uint32_t)i);
+    }
+    return out;
 }
 
 template <class T>
@@ -432,8 +473,10 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         boxes.push_back(s.boxes[idx]);
         return (uint32_t)boxes.size() - 1;
     };
+    const size_t n_tree_prims = s.tree.order.size();
     for (size_t k = 0; k < leaf.size(); k++) {
-        const uint32_t id = s.tree.order[k];
+        // the tree's primitives in leaf order, then the media that enclose the scene
+        const uint32_t id = k < n_tree_prims ? s.tree.order[k] : s.enclosing[k - n_tree_prims];
         const rt_prim_ref &pr = s.prims[id];
         const uint32_t kind = pr.kind & 0xffu;
         rt::LeafPrim lp{(pr.kind & 0x1ffu) | (pr.xform << 16) | (rare_shade(pr) ? rt::kRareShade : 0u), 0, id,
@@ -527,6 +570,8 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     if ((rc = upload(db, imgs, &D.images))) return rc;
     D.n_nodes = (uint32_t)nodes.size();
     D.n_prims = (uint32_t)leaf.size();
+    D.n_tree_prims = (uint32_t)n_tree_prims;
+    D.n_enclosing = (uint32_t)s.enclosing.size();
     D.n_pairs = n_pairs;
     D.root_ref = nodes.empty() ? 0u : ref_of(0);
     for (int c = 0; c < 3; c++) {
@@ -708,6 +753,20 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
                     bounds[i].lo[k] > bounds[i].hi[k])
                     return fail(RT_ERR_INVALID, "primitive %zu has no finite bounding box", i);
         }
+        s->enclosing = find_enclosing(*s, bounds);
+        std::vector<uint32_t> in_tree; // primitives the tree is built over, when some are left out
+        if (!s->enclosing.empty()) {
+            size_t e = 0;
+            for (uint32_t i = 0; i < (uint32_t)bounds.size(); i++) {
+                if (e < s->enclosing.size() && s->enclosing[e] == i) {
+                    e++;
+                    continue;
+                }
+                bounds[in_tree.size()] = bounds[i];
+                in_tree.push_back(i);
+            }
+            bounds.resize(in_tree.size());
+        }
         std::string err;
         int rc;
         if (opts && (opts->flags & RT_BUILD_ON_DEVICE)) {
@@ -719,6 +778,8 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
                                 opts ? opts->split_method : (uint32_t)RT_SPLIT_SAH, s->tree, err);
         }
         if (rc != RT_OK) return fail(rc, "%s", err.c_str());
+        if (!in_tree.empty())
+            for (uint32_t &id : s->tree.order) id = in_tree[id];
         s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *out = s.release();
         return RT_OK;
@@ -740,14 +801,14 @@ void rt_scene_destroy(rt_scene *s) {
 
 int rt_scene_world_bound(const rt_scene *s, float out[6]) { // bvh.rs:728-734
     if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    Aabb b = rt::empty_box();
     if (!s->tree.nodes.empty()) {
-        memcpy(out, s->tree.nodes[0].lo, 12);
-        memcpy(out + 3, s->tree.nodes[0].hi, 12);
-    } else {
-        Aabb e = rt::empty_box();
-        memcpy(out, e.lo, 12);
-        memcpy(out + 3, e.hi, 12);
+        memcpy(b.lo, s->tree.nodes[0].lo, 12);
+        memcpy(b.hi, s->tree.nodes[0].hi, 12);
     }
+    for (uint32_t id : s->enclosing) b = join(b, prim_bounds(*s, s->prims[id])); // they belong to the scene
+    memcpy(out, b.lo, 12);
+    memcpy(out + 3, b.hi, 12);
     return RT_OK;
 }
 
@@ -763,6 +824,8 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
         for (auto &kv : s->devices) out->device_bytes = kv.second->bytes;
     }
     out->build_ms = s->build_ms;
+    out->n_enclosing = (uint32_t)s->enclosing.size();
+    for (size_t k = 0; k < s->enclosing.size() && k < 4; k++) out->enclosing[k] = s->enclosing[k];
     return RT_OK;
 }
 

@@ -77,7 +77,10 @@ struct SceneDev {
     const ImageDev *images;
     const float *perlin_vec;
     const int32_t *perlin_perm;
-    uint32_t n_nodes, n_prims; // n_nodes: LinearBVHNode count of the tree (0 = empty scene)
+    uint32_t n_nodes, n_prims; // n_nodes: LinearBVHNode count of the tree (0 = empty tree)
+    // Media that enclose the scene are not in the tree: their entries follow the tree's
+    // n_tree_prims primitives in `leaf`, and every ray tests them before it starts traversing.
+    uint32_t n_tree_prims, n_enclosing;
     uint32_t n_pairs;          // interior records in `nodes`
     uint32_t root_ref;         // reference to the root (a leaf when the tree is a single node)
     uint32_t stack_lds;        // stack levels per lane kept in LDS; deeper entries use private memory

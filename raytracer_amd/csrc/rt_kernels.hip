@@ -384,7 +384,23 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                     inv = mk(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
                     sp = 0;
                     L.best = RT_MISS;
-                    if (S.n_nodes) {
+                    // Media that enclose the scene are not in the tree: every ray tests them here,
+                    // where all the lanes that were just fed run the same code, instead of inside a
+                    // leaf round.  A hit shortens the ray before the traversal starts.
+                    bool occluded = false;
+                    for (uint32_t e = 0; e < S.n_enclosing; e++) {
+                        const uint32_t slot = S.n_tree_prims + e;
+                        const LeafPrim lp = S.leaf[slot];
+                        if (COUNT) cnt.prims[RT_MEDIUM]++;
+                        float t;
+                        if (medium_test(S, lp, L.ray, inv, t)) {
+                            L.ray.t_max = t;
+                            L.best = slot | ((lp.kind & kRareShade) ? kBestRare : 0u);
+                            L.a0 = L.a1 = L.a2 = 0.0f;
+                            if (ANY) occluded = true;
+                        }
+                    }
+                    if (S.n_nodes && !occluded) {
                         if (COUNT) cnt.nodes++;
                         float t;
                         float4 r0 = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f);

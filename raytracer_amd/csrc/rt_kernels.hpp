@@ -91,6 +91,8 @@ struct LaunchShape {
 #define RT_GLOBAL_WAVES 6
 #endif
 constexpr uint32_t kGlobalWaves = RT_GLOBAL_WAVES;
+// Media enclosing the scene that are kept out of the tree, at most.
+constexpr uint32_t kMaxEnclosing = 4;
 // Stack entries a lane can keep in a private array beyond its LDS levels.
 constexpr uint32_t kSpillLevels = 56;
 // Dynamic LDS of a trace workgroup (interior records for the LDS-resident shape + stacks).

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import abi, pcg32
 from .scene import SceneData, identity, look_at, perspective_camera, rotate, rotate_y, scale, translate
-from .scenes import _legacy_camera, earth_texture
+from .scenes import _legacy_camera, earth_image
 
 try:  # Python >= 3.11
     import tomllib as _toml
@@ -61,8 +61,8 @@ class _TomlBuilder:
             odd, even = self.texture(spec["odd"]), self.texture(spec["even"])
             return s.add_texture(abi.RT_TEX_CHECKER, a=odd, b=even, scale=float(spec.get("scale", 10.0)))
         if kind == "Image":
-            # the only image the scenes name is the earth map; its stand-in is procedural
-            return s.add_texture(abi.RT_TEX_IMAGE, a=s.add_image(earth_texture()))
+            # the only image the scenes name is the earth map (a decoded fixture; see scenes.earth_image)
+            return s.add_texture(abi.RT_TEX_IMAGE, a=s.add_image(earth_image(spec.get("file_name", "earthmap.jpg"))))
         if kind == "Noise":
             self.uses_noise = True
             return s.add_texture(abi.RT_TEX_NOISE, scale=float(spec["scale"]))

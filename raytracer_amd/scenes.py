@@ -116,6 +116,19 @@ def earth_texture(width=1024, height=512):
     return img.astype(np.uint8)
 
 
+def earth_image(file_name="earthmap.jpg"):
+    """The Image texture the legacy scenes name (test/week.toml:101, test/globe.toml): the
+    reference's test/earthmap.jpg, decoded once to RGB8 and kept as a fixture
+    (tests/golden/earthmap_rgb8.npz, written by tests/golden/make_reference_assets.py).  A tree
+    without the fixture falls back to the procedural stand-in of the same size."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        "earthmap_rgb8.npz")
+    if os.path.basename(file_name) == "earthmap.jpg" and os.path.exists(path):
+        return np.load(path)["rgb8"]
+    return earth_texture()
+
+
 def next_week(boxes_per_side=20, cube_count=1000):
     """test/week.toml: RandomBoxes ground, light, moving sphere, glass, metal,
     a glass ball filled with blue fog, a thin global fog, an image-textured
@@ -140,7 +153,7 @@ def next_week(boxes_per_side=20, cube_count=1000):
     s.add_sphere((360.0, 150.0, 145.0), 70.0, glass)
     s.add_medium(0.2, s.isotropic((0.2, 0.4, 0.9)), sphere=((360.0, 150.0, 145.0), 70.0))
     s.add_medium(0.0001, s.isotropic((1.0, 1.0, 1.0)), sphere=((0.0, 0.0, 0.0), 5000.0))
-    earth = s.add_texture(abi.RT_TEX_IMAGE, a=s.add_image(earth_texture()))
+    earth = s.add_texture(abi.RT_TEX_IMAGE, a=s.add_image(earth_image()))
     # the reference sphere is z-polar; the scene is y-up: rotate the pole onto +y
     s.add_gsphere(translate((400.0, 200.0, 400.0)) @ rotate([1.0, 0.0, 0.0], -90.0), 100.0,
                   material=s.lambertian(texture=earth))

@@ -237,3 +237,52 @@ def test_missing_library_is_an_import_error(monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/librt355.so")
     with pytest.raises(ImportError):
         lib.load()
+
+
+def test_media_that_enclose_the_scene_are_kept_out_of_the_tree(scene_cache):
+    """A medium whose sphere contains the box around every other primitive is not given to
+    the tree (every ray would meet it there): the library and the oracle pick the same ones,
+    the tree is the tree of the scene without them, and the world bound still covers them."""
+    _, _, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    gi, oi = g.info(), o.info()
+    prims = fr._keep["prims"]
+    assert gi.n_enclosing == oi.n_enclosing == 1 and gi.enclosing[0] == oi.enclosing[0]
+    fog = prims[gi.enclosing[0]]
+    assert fog["kind"] & 0xFF == abi.RT_MEDIUM
+    assert fr._keep["spheres"][fr._keep["media"][fog["index"]]["boundary_index"]]["r"] == 5000.0
+    assert len(g.prim_order()) == gi.n_prims - 1 and gi.enclosing[0] not in set(g.prim_order())
+    assert list(g.world_bound()) == list(o.world_bound()) == [-5000.0] * 3 + [5000.0] * 3
+    root = g.nodes()[0]
+    assert root["hi"][1] < 1000.0  # the tree's own root is the size of the scene, not of the fog
+
+    def build(n_around, r_small=3.0, with_solid=True):
+        s = SceneData()
+        s.lambertian((1, 1, 1))
+        iso = s.isotropic((1, 1, 1))
+        if with_solid:
+            for k in range(20):
+                s.add_sphere((k - 10.0, 0.5 * k, 2.0), 0.7)
+        s.add_medium(0.3, iso, sphere=((0.0, 0.0, 0.0), r_small))  # inside the scene: stays in the tree
+        for k in range(n_around):
+            s.add_medium(0.01, iso, sphere=((0.1 * k, 0.0, 0.0), 100.0 + k))
+        return s.freeze()
+
+    for n_around, expect in ((0, 0), (1, 1), (4, 4), (6, 4)):
+        fr2 = build(n_around)
+        for split in range(4):
+            g2, o2 = lib.Scene(fr2, 2, split), orc.OracleScene(fr2, 2, split)
+            i2 = g2.info()
+            assert i2.n_enclosing == o2.info().n_enclosing == expect
+            assert list(i2.enclosing[:expect]) == list(range(21, 21 + expect))
+            assert g2.nodes().tobytes() == o2.nodes().tobytes() and (g2.prim_order() == o2.prim_order()).all()
+            assert (g2.world_bound() == o2.world_bound()).all()
+        # the tree is the one of the same scene without the media kept out of it
+        if n_around == 4:
+            assert lib.Scene(fr2).nodes().tobytes() == lib.Scene(build(0)).nodes().tobytes()
+    # a scene of media only: nothing to enclose, nothing is kept out
+    fr3 = build(2, with_solid=False)
+    assert lib.Scene(fr3).info().n_enclosing == orc.OracleScene(fr3).info().n_enclosing == 0
+    # a sphere that cuts through the scene's box is not enclosing
+    fr4 = build(0, r_small=9.0)
+    assert lib.Scene(fr4).info().n_enclosing == 0

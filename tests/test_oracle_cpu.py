@@ -310,7 +310,12 @@ def test_bvh_equals_brute_force(split):
     assert (a["prim"] == b["prim"]).all() and (a["t"] == b["t"]).all()
     assert ((a["prim"] != abi.RT_MISS) == (o.occluded(rays) != 0)).all()
     nodes, order = o.nodes(), o.prim_order()
-    assert sorted(order) == list(range(o.info().n_prims))
+    info = o.info()
+    # every primitive is in exactly one leaf, except the medium around the whole scene, which
+    # is kept out of the tree and tested before the traversal
+    kept_out = list(info.enclosing[:info.n_enclosing])
+    assert len(kept_out) == 1 and (o.frozen._keep["prims"]["kind"][kept_out[0]] & 0xFF) == abi.RT_MEDIUM
+    assert sorted(list(order) + kept_out) == list(range(info.n_prims))
     leaves = nodes[nodes["primitive_count"] > 0]
     assert leaves["primitive_count"].sum() == len(order)
     inner = np.nonzero(nodes["primitive_count"] == 0)[0]
