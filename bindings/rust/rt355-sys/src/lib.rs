@@ -89,7 +89,7 @@ pub struct rt_render_opts { pub width: u32, pub height: u32, pub spp: u32, pub m
 pub struct rt_stats {
     pub paths: u64, pub segments: u64, pub nodes_visited: u64, pub prims_tested: [u64; 8],
     pub trace_launches: u64, pub trace_ms: f64, pub total_ms: f64, pub batches: u32, pub max_bounce: u32,
-    pub bounce_rays: [u64; 64],
+    pub bounce_rays: [u64; 64], pub occlusion_rays: u64,
 }
 
 #[repr(C)] pub struct rt_scene { _opaque: [u8; 0] }
@@ -104,6 +104,7 @@ extern "C" {
     pub fn rt_scene_upload(scene: *mut rt_scene, device: c_int) -> c_int;
     pub fn rt_intersect(scene: *mut rt_scene, rays: *const rt_ray, n: usize, hits: *mut rt_hit, device: c_int) -> c_int;
     pub fn rt_intersect_dev(scene: *mut rt_scene, d_rays: *const rt_ray, n: usize, d_hits: *mut rt_hit, device: c_int, stream: *mut c_void) -> c_int;
+    pub fn rt_intersect_dev_noalloc(scene: *mut rt_scene, d_rays: *const rt_ray, n: usize, d_hits: *mut rt_hit, device: c_int, stream: *mut c_void) -> c_int;
     pub fn rt_intersect_count(scene: *mut rt_scene, d_rays: *const rt_ray, n: usize, d_hits: *mut rt_hit, device: c_int, out: *mut u64) -> c_int;
     pub fn rt_occluded(scene: *mut rt_scene, rays: *const rt_ray, n: usize, out: *mut u8, device: c_int) -> c_int;
     pub fn rt_occluded_dev(scene: *mut rt_scene, d_rays: *const rt_ray, n: usize, d_out: *mut u8, device: c_int, stream: *mut c_void) -> c_int;

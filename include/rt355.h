@@ -253,6 +253,17 @@ typedef struct rt_camera {
 #define RT_RENDER_TIMING 2u   /* bracket every trace launch with HIP events       */
 #define RT_RENDER_RAW_FILM 4u /* with a filter: leave {sum of w*L, sum of w} per pixel
                                  (shards are summed before rt_film_resolve_dev)   */
+/* Direct lighting by shadow rays.  At every hit on a Lambertian surface one point q on one
+ * light is sampled (lights: rectangles without instance transform whose material is a
+ * DiffuseLight with a solid colour), the ray Interaction::spawn_ray_to(q)
+ * (shapes/src/interaction.rs:102-116: origin offset by offset_ray_origin towards q, direction
+ * q - origin un-normalised, t_max = 1 - 0.0001) goes through the any-hit traversal
+ * (BVH::does_intersect, bvh.rs:801-863), and if it is not occluded
+ * throughput * albedo / pi * emitted * cos cos' area n_lights / distance^2 is added to the
+ * path's radiance; the light a path reaches by its next segment then adds nothing.  Such
+ * frames use one launch per bounce plus one any-hit launch per bounce.  A different estimator
+ * from the default one (the legacy scenes' scattering_mode = "Sphere"): images differ. */
+#define RT_RENDER_DIRECT_LIGHT 8u
 
 /* Reconstruction filters, colour/src/filters/{box,triangle,gaussian,mitchell,
  * lanczos_sinc}.rs.  RT_FILTER_NONE keeps the legacy scenes' behaviour: a pixel
@@ -311,7 +322,7 @@ typedef struct rt_render_opts {
 
 typedef struct rt_stats {
     uint64_t paths;
-    uint64_t segments;      /* closest-hit ray segments traced                  */
+    uint64_t segments;      /* ray segments traced: closest-hit + occlusion_rays   */
     uint64_t nodes_visited; /* with RT_RENDER_COUNTERS                           */
     uint64_t prims_tested[8]; /* per rt_prim_kind, with RT_RENDER_COUNTERS        */
     uint64_t trace_launches;
@@ -319,7 +330,8 @@ typedef struct rt_stats {
     double total_ms; /* first launch -> framebuffer resolved, device time        */
     uint32_t batches;
     uint32_t max_bounce;
-    uint64_t bounce_rays[64]; /* ray segments traced at bounce 0..63 */
+    uint64_t bounce_rays[64]; /* closest-hit ray segments traced at bounce 0..63 */
+    uint64_t occlusion_rays;  /* any-hit rays (RT_RENDER_DIRECT_LIGHT), part of `segments` */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

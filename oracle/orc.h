@@ -65,6 +65,9 @@ void orc_pcg32_floats(uint64_t seq, float *out, size_t n);
 float orc_math_eval(int fn, float a, float b); /* 0 sin 1 cos 2 log 3 atan2 4 acos 5 gamma(a) */
 void orc_offset_ray_origin(const float p[3], const float err[3], const float n[3], const float w[3],
                            float out[3]);
+/* Interaction::spawn_ray_to / spawn_ray_intersect, shapes/src/interaction.rs:102-133 */
+void orc_spawn_ray_to_test(const float p[3], const float err[3], const float n[3], const float target[3],
+                           float time, rt_ray *out);
 const char *orc_last_error(void);
 
 #ifdef __cplusplus

@@ -114,6 +114,15 @@ int orc_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, orc_scen
             s->images[i].rgb8 = dup_mem(d->images[i].rgb8, (size_t)d->images[i].w * d->images[i].h * 3);
         }
     }
+    /* lights for direct lighting: plain rectangles with a solid-colour DiffuseLight */
+    s->lights = (uint32_t *)calloc(d->n_prims ? d->n_prims : 1, sizeof *s->lights);
+    for (uint32_t i = 0; i < d->n_prims && d->n_materials && d->n_textures; i++) {
+        const rt_prim_ref *p = &d->prims[i];
+        if ((p->kind & 0xffu) != RT_RECT || p->xform) continue;
+        const rt_material *m = &d->materials[p->material];
+        if (m->kind == RT_MAT_DIFFUSE_LIGHT && d->textures[m->texture].kind == RT_TEX_SOLID)
+            s->lights[s->n_lights++] = i;
+    }
     int rc = orc_build(s, opts);
     if (rc != RT_OK) { orc_scene_destroy(s); return rc; }
     *out = s;
@@ -127,7 +136,7 @@ void orc_scene_destroy(orc_scene *s) {
     free(s->prims); free(s->spheres); free(s->msph); free(s->tri_verts); free(s->tri_uvs);
     free(s->tri_normals); free(s->rects); free(s->boxes); free(s->gsph); free(s->xforms);
     free(s->media); free(s->materials); free(s->textures); free(s->images); free(s->perlin_vec);
-    free(s->perlin_perm); free(s->nodes); free(s->order);
+    free(s->perlin_perm); free(s->nodes); free(s->order); free(s->lights);
     free(s);
 }
 
@@ -198,7 +207,7 @@ typedef struct {
     float *rad; /* 3 floats per path, indexed from first */
     uint32_t *segs;
     uint64_t first;
-    uint64_t segments;
+    uint64_t segments, occlusion;
 } job;
 
 static void surf_to_hit(const orc_surf *h, rt_hit *o) {
@@ -244,10 +253,12 @@ static void *run_job(void *arg) {
                 miss_hit(&j->hits[i]);
             }
         } else {
+            uint32_t occ = 0;
             uint32_t n = orc_trace_path(s, j->cam, j->opts, j->first + i, j->rad + 3 * i,
-                                        j->want_counters ? j->counters : NULL);
-            if (j->segs) j->segs[i] = n;
+                                        j->want_counters ? j->counters : NULL, &occ);
+            if (j->segs) j->segs[i] = n + occ;
             j->segments += n;
+            j->occlusion += occ;
         }
     }
     orc_thread_release();
@@ -273,6 +284,7 @@ static int run_jobs(job *proto, size_t n, int threads) {
     for (int t = 0; t < threads; t++) {
         for (int k = 0; k < 9; k++) proto->counters[k] += jobs[t].counters[k];
         proto->segments += jobs[t].segments;
+        proto->occlusion += jobs[t].occlusion;
     }
     free(jobs);
     free(tid);
@@ -420,7 +432,7 @@ static int render_filtered(const orc_scene *s, const rt_camera *cam, const rt_re
     size_t npix = (size_t)W * H;
     float *rad = (float *)calloc(npix * spp * 3, sizeof(float));
     if (!rad) return RT_ERR_NOMEM;
-    uint64_t segments = 0, paths = 0, counters[9] = {0};
+    uint64_t segments = 0, occlusion = 0, paths = 0, counters[9] = {0};
     int want = (opts->flags & RT_RENDER_COUNTERS) != 0;
     for (size_t p = 0; p < npix; p++) {
         if (!pixel_owned(opts, (uint32_t)(p % W), (uint32_t)(p / W))) continue;
@@ -430,6 +442,7 @@ static int render_filtered(const orc_scene *s, const rt_camera *cam, const rt_re
         j.first = (uint64_t)p * spp; j.want_counters = want;
         run_jobs(&j, spp, 1);
         segments += j.segments;
+        occlusion += j.occlusion;
         paths += spp;
         for (int k = 0; k < 9; k++) counters[k] += j.counters[k];
     }
@@ -471,7 +484,8 @@ static int render_filtered(const orc_scene *s, const rt_camera *cam, const rt_re
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->paths = paths;
-        stats->segments = segments;
+        stats->segments = segments + occlusion;
+        stats->occlusion_rays = occlusion;
         stats->nodes_visited = counters[0];
         for (int k = 0; k < 8; k++) stats->prims_tested[k] = counters[1 + k];
     }
@@ -491,7 +505,7 @@ int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *o
     size_t chunk_pix = 65536 / opts->spp ? 65536 / opts->spp : 1;
     float *rad = (float *)malloc(chunk_pix * opts->spp * 3 * sizeof(float));
     if (!rad) return RT_ERR_NOMEM;
-    uint64_t segments = 0, paths = 0, counters[9] = {0};
+    uint64_t segments = 0, occlusion = 0, paths = 0, counters[9] = {0};
     int want = (opts->flags & RT_RENDER_COUNTERS) != 0;
     for (size_t p0 = 0; p0 < npix; p0 += chunk_pix) {
         size_t p1 = p0 + chunk_pix < npix ? p0 + chunk_pix : npix;
@@ -509,6 +523,7 @@ int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *o
         if ((opts->shard_count ? opts->shard_count : 1) == 1) {
             run_jobs(&j, n, threads);
             segments += j.segments;
+            occlusion += j.occlusion;
             paths += n;
             for (int k = 0; k < 9; k++) counters[k] += j.counters[k];
         } else {
@@ -519,9 +534,11 @@ int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *o
                 jj.rad = rad + (p - p0) * opts->spp * 3;
                 jj.first = (uint64_t)p * opts->spp;
                 jj.segments = 0;
+                jj.occlusion = 0;
                 memset(jj.counters, 0, sizeof jj.counters);
                 run_jobs(&jj, opts->spp, 1);
                 segments += jj.segments;
+                occlusion += jj.occlusion;
                 paths += opts->spp;
                 for (int k = 0; k < 9; k++) counters[k] += jj.counters[k];
             }
@@ -544,7 +561,8 @@ int orc_render(const orc_scene *s, const rt_camera *cam, const rt_render_opts *o
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->paths = paths;
-        stats->segments = segments;
+        stats->segments = segments + occlusion;
+        stats->occlusion_rays = occlusion;
         stats->nodes_visited = counters[0];
         for (int k = 0; k < 8; k++) stats->prims_tested[k] = counters[1 + k];
         stats->total_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
@@ -600,6 +618,11 @@ float orc_math_eval(int fn, float a, float b) {
     case 5: return orc_gamma((int)a);
     default: return 0.0f;
     }
+}
+void orc_spawn_ray_to_test(const float p[3], const float err[3], const float n[3], const float target[3],
+                           float time, rt_ray *out) {
+    orc_spawn_ray_to(v3_make(p[0], p[1], p[2]), v3_make(err[0], err[1], err[2]), v3_make(n[0], n[1], n[2]),
+                     v3_make(target[0], target[1], target[2]), time, out);
 }
 void orc_offset_ray_origin(const float p[3], const float err[3], const float n[3], const float w[3],
                            float out[3]) {

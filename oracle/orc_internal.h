@@ -60,6 +60,9 @@ struct orc_scene {
     float *perlin_vec;
     int32_t *perlin_perm;
     float background[3];
+    /* lights of RT_RENDER_DIRECT_LIGHT: rectangles without instance transform whose material is a
+     * DiffuseLight with a solid colour, in primitive order */
+    uint32_t n_lights, *lights;
     /* Media that enclose the scene are kept out of the tree (see orc_build): every ray meets
      * them, so they are tested once per ray, before the traversal, in this order. */
     uint32_t n_enclosing, enclosing[ORC_MAX_ENCLOSING];
@@ -110,8 +113,10 @@ void orc_thread_release(void);
 void orc_camera_sample(const rt_render_opts *opts, uint32_t px, uint32_t py, uint32_t s, orc_rng *rng, float u[5]);
 void orc_path_setup(const rt_camera *cam, const rt_render_opts *opts, uint64_t path, orc_rng *rng,
                     rt_ray *ray);
+/* Returns the closest-hit segments of the path; *occlusion receives its shadow rays. */
 uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
-                        uint64_t path, float rgb[3], uint64_t counters[9]);
+                        uint64_t path, float rgb[3], uint64_t counters[9], uint32_t *occlusion);
 v3 orc_offset_origin(v3 p, v3 err, v3 n, v3 w);
+void orc_spawn_ray_to(v3 p, v3 err, v3 n, v3 target, float time, rt_ray *out);
 
 #endif

@@ -4,7 +4,8 @@
  *
  * Camera: colour/src/camera/perspective.rs:54-78, geometry/src/sampling.rs:4-22
  * (second branch uses x / y), geometry/src/transform.rs:530-552.
- * Next-ray origin: shapes/src/interaction.rs:86-99, geometry/src/lib.rs:129-151.
+ * Next-ray origin: shapes/src/interaction.rs:86-99, geometry/src/lib.rs:129-151; shadow rays:
+ * spawn_ray_to / spawn_ray_intersect, interaction.rs:102-133.
  * RNG: geometry/src/rng.rs.  Materials, textures, Perlin noise and constant
  * media have no code in the reference; they follow the schema of the scene
  * files under test/ (Lambertian / Metallic / Dielectric / DiffuseLight,
@@ -24,6 +25,18 @@ v3 orc_offset_origin(v3 p, v3 err, v3 n, v3 w) { /* lib.rs:129-151 */
     if (off.y > 0.0f) po.y = next_float_up(po.y); else if (off.y < 0.0f) po.y = next_float_down(po.y);
     if (off.z > 0.0f) po.z = next_float_up(po.z); else if (off.z < 0.0f) po.z = next_float_down(po.z);
     return po;
+}
+
+/* Interaction::spawn_ray_to, interaction.rs:102-116 (spawn_ray_intersect, :119-133, is the same
+ * with the other interaction's point as the target): the origin is offset towards the target,
+ * the direction is target - origin, not normalised, and the ray ends just short of the target. */
+void orc_spawn_ray_to(v3 p, v3 err, v3 n, v3 target, float time, rt_ray *out) {
+    v3 o = orc_offset_origin(p, err, n, v3_sub(target, p));
+    v3 d = v3_sub(target, o);
+    out->o[0] = o.x; out->o[1] = o.y; out->o[2] = o.z;
+    out->d[0] = d.x; out->d[1] = d.y; out->d[2] = d.z;
+    out->t_max = 1.0f - 0.0001f;
+    out->time = time;
 }
 
 /* concentric_sample_disk, sampling.rs:4-22 */
@@ -546,21 +559,29 @@ static v3 random_in_unit_sphere(orc_rng *rng) {
 }
 static v3 reflect(v3 v, v3 n) { return v3_sub(v, v3_scale(n, 2.0f * v3_dot(v, n))); }
 
-/* One path.  Returns the number of ray segments traced. */
+/* One path.  Returns the number of closest-hit segments traced; *occlusion (may be NULL)
+ * receives the number of shadow rays.
+ * With RT_RENDER_DIRECT_LIGHT every hit on a Lambertian surface samples one point on one light
+ * and sends spawn_ray_to(point) through the any-hit traversal; the draws follow the scatter
+ * direction's (light number only when there are several lights, then the two coordinates of the
+ * point), and a light the path reaches by its very next segment adds nothing (its share was
+ * taken by the shadow ray). */
 uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_render_opts *opts,
-                        uint64_t path, float rgb[3], uint64_t counters[9]) {
+                        uint64_t path, float rgb[3], uint64_t counters[9], uint32_t *occlusion) {
     orc_rng rng;
     rt_ray ray;
     orc_path_setup(cam, opts, path, &rng, &ray);
     v3 beta = v3_make(1.0f, 1.0f, 1.0f);
     v3 L = v3_make(0.0f, 0.0f, 0.0f);
-    uint32_t segments = 0;
+    uint32_t segments = 0, shadow_rays = 0;
+    const int direct = (opts->flags & RT_RENDER_DIRECT_LIGHT) && s->n_lights;
+    int skip_emission = 0; /* the previous vertex sampled the lights */
     for (uint32_t depth = 0; depth < opts->max_depth; depth++) {
         orc_surf h;
         segments++;
         if (!orc_closest(s, &ray, &h, counters)) {
-            L = v3_make(beta.x * s->background[0], beta.y * s->background[1],
-                        beta.z * s->background[2]);
+            L = v3_add(L, v3_make(beta.x * s->background[0], beta.y * s->background[1],
+                                  beta.z * s->background[2]));
             break;
         }
         v3 d = v3_make(ray.d[0], ray.d[1], ray.d[2]);
@@ -570,7 +591,7 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
         v3 dir;
         if (m->kind == RT_MAT_DIFFUSE_LIGHT) {
             v3 e = texture_value(s, m->texture, h.u, h.v, h.p);
-            L = v3_make(beta.x * e.x, beta.y * e.y, beta.z * e.z);
+            if (!skip_emission) L = v3_add(L, v3_make(beta.x * e.x, beta.y * e.y, beta.z * e.z));
             break;
         } else if (m->kind == RT_MAT_LAMBERTIAN) {
             v3 r = random_in_unit_sphere(&rng);
@@ -578,6 +599,36 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = nf;
             dir = v3_norm(dir);
             v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
+            if (direct) {
+                uint32_t li = 0;
+                if (s->n_lights > 1) {
+                    li = (uint32_t)(orc_rng_f(&rng) * (float)s->n_lights);
+                    if (li >= s->n_lights) li = s->n_lights - 1;
+                }
+                float u1 = orc_rng_f(&rng), u2 = orc_rng_f(&rng);
+                const rt_prim_ref *lp = &s->prims[s->lights[li]];
+                const rt_rect *lr = &s->rects[lp->index];
+                const rt_texture *lt = &s->textures[s->materials[lp->material].texture];
+                float qa = lr->a0 + u1 * (lr->a1 - lr->a0), qb = lr->b0 + u2 * (lr->b1 - lr->b0);
+                v3 q = lr->axis == 0 ? v3_make(lr->k, qa, qb)
+                                     : (lr->axis == 1 ? v3_make(qa, lr->k, qb) : v3_make(qa, qb, lr->k));
+                rt_ray sr;
+                orc_spawn_ray_to(h.p, h.perr, h.n, q, ray.time, &sr);
+                v3 sd = v3_make(sr.d[0], sr.d[1], sr.d[2]);
+                float d2 = v3_dot(sd, sd), cs = v3_dot(sd, nf), cl = fabsf(v3_get(sd, (int)lr->axis));
+                if (cs > 0.0f && cl > 0.0f && d2 > 0.0f) {
+                    shadow_rays++;
+                    if (!orc_any(s, &sr)) {
+                        /* albedo / pi * emitted * (cs / |d|) (cl / |d|) / |d|^2 * area * n_lights */
+                        float area = (lr->a1 - lr->a0) * (lr->b1 - lr->b0);
+                        float scale = area * (float)s->n_lights * 0.318309886f;
+                        float g = (cs * cl) / (d2 * d2) * scale;
+                        L = v3_add(L, v3_make(beta.x * a.x * lt->rgb[0] * g, beta.y * a.y * lt->rgb[1] * g,
+                                              beta.z * a.z * lt->rgb[2] * g));
+                    }
+                }
+            }
+            skip_emission = direct;
             beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
         } else if (m->kind == RT_MAT_METALLIC) {
             v3 r = random_in_unit_sphere(&rng);
@@ -586,6 +637,7 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
             dir = v3_norm(dir);
             v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
             beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+            skip_emission = 0;
         } else if (m->kind == RT_MAT_DIELECTRIC) {
             float ratio = front ? 1.0f / m->ior : m->ior;
             float cos_t = sel_min(v3_dot(v3_neg(d), nf), 1.0f);
@@ -607,10 +659,12 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
                 dir = v3_add(perp, par);
             }
             dir = v3_norm(dir);
+            skip_emission = 0;
         } else { /* RT_MAT_ISOTROPIC */
             dir = v3_norm(random_in_unit_sphere(&rng));
             v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
             beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
+            skip_emission = 0;
         }
         v3 no = orc_offset_origin(h.p, h.perr, h.n, dir); /* spawn_ray, interaction.rs:86-99 */
         ray.o[0] = no.x; ray.o[1] = no.y; ray.o[2] = no.z;
@@ -618,5 +672,6 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
         ray.t_max = INFINITY;
     }
     rgb[0] = L.x; rgb[1] = L.y; rgb[2] = L.z;
+    if (occlusion) *occlusion = shadow_rays;
     return segments;
 }

@@ -23,7 +23,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_METALLIC, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE, RT_TEX_NOISE, RT_TEX_CHECKER_UV = range(5)
 # rt_split_method == SplitMethod (shapes/src/bvh.rs:10-22)
 RT_SPLIT_SAH, RT_SPLIT_HLBVH, RT_SPLIT_MIDDLE, RT_SPLIT_EQUAL_COUNTS = range(4)
-RT_RENDER_COUNTERS, RT_RENDER_TIMING, RT_RENDER_RAW_FILM = 1, 2, 4
+RT_RENDER_COUNTERS, RT_RENDER_TIMING, RT_RENDER_RAW_FILM, RT_RENDER_DIRECT_LIGHT = 1, 2, 4, 8
 (RT_FILTER_NONE, RT_FILTER_BOX, RT_FILTER_TRIANGLE, RT_FILTER_GAUSSIAN, RT_FILTER_MITCHELL,
  RT_FILTER_LANCZOS) = range(6)
 
@@ -113,7 +113,7 @@ class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("prims_tested", C.c_uint64 * 8), ("trace_launches", C.c_uint64),
                 ("trace_ms", C.c_double), ("total_ms", C.c_double), ("batches", C.c_uint32),
-                ("max_bounce", C.c_uint32), ("bounce_rays", C.c_uint64 * 64)]
+                ("max_bounce", C.c_uint32), ("bounce_rays", C.c_uint64 * 64), ("occlusion_rays", C.c_uint64)]
 
 
 # sizeof() table in the order rt_abi_sizes() reports it

@@ -96,6 +96,11 @@ struct DeviceBuffers {
     float4 *radiance = nullptr;
     uint32_t *counts = nullptr;
     std::vector<void *> ws_allocs;
+    // shadow rays of RT_RENDER_DIRECT_LIGHT (allocated when a frame first asks for them)
+    rt::ShadowQueue shadow{};
+    uint32_t *shadow_counts = nullptr;
+    uint32_t shadow_paths = 0, shadow_depth = 0;
+    std::vector<void *> shadow_allocs;
     // one block cursor per stream the trace entry points were called on: launches on a stream
     // run one after another, so they can share a word that is cleared in front of each
     std::mutex cursor_lock;
@@ -307,6 +312,8 @@ int upload(DeviceBuffers &db, const std::vector<T> &host, const T **dev) {
 void release(DeviceBuffers &db) {
     for (void *p : db.allocs) (void)hipFree(p);
     for (void *p : db.ws_allocs) (void)hipFree(p);
+    for (void *p : db.shadow_allocs) (void)hipFree(p);
+    db.shadow_allocs.clear();
     for (auto &kv : db.cursors) (void)hipFree(kv.second);
     db.allocs.clear();
     db.ws_allocs.clear();
@@ -561,6 +568,25 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     if ((rc = upload(db, s.textures, &D.textures))) return rc;
     if ((rc = upload(db, s.perlin_vec, &D.perlin_vec))) return rc;
     if ((rc = upload(db, s.perlin_perm, &D.perlin_perm))) return rc;
+    // lights of RT_RENDER_DIRECT_LIGHT: rectangles without instance transform whose material is a
+    // DiffuseLight with a solid colour, in primitive order
+    std::vector<rt::LightDev> lights;
+    for (const rt_prim_ref &pr : s.prims) {
+        if ((pr.kind & 0xffu) != RT_RECT || pr.xform || pr.material >= s.materials.size()) continue;
+        const rt_material &m = s.materials[pr.material];
+        if (m.kind != RT_MAT_DIFFUSE_LIGHT || m.texture >= s.textures.size() ||
+            s.textures[m.texture].kind != RT_TEX_SOLID)
+            continue;
+        const rt_rect &r = s.rects[pr.index];
+        const rt_texture &t = s.textures[m.texture];
+        lights.push_back(rt::LightDev{r.axis, r.k, r.a0, r.a1, r.b0, r.b1, 0.0f, {t.rgb[0], t.rgb[1], t.rgb[2]}, {0, 0}});
+    }
+    for (rt::LightDev &l : lights) {
+        const float area = (l.a1 - l.a0) * (l.b1 - l.b0);
+        l.scale = area * (float)lights.size() * 0.318309886f;
+    }
+    if ((rc = upload(db, lights, &D.lights))) return rc;
+    D.n_lights = (uint32_t)lights.size();
     std::vector<rt::ImageDev> imgs;
     for (size_t i = 0; i < s.images.size(); i++) {
         const uint8_t *px = nullptr;
@@ -693,6 +719,30 @@ int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
     if ((rc = take(count_words(depth) * sizeof(uint32_t), (void **)&db.counts))) return rc;
     db.ws_paths = paths;
     db.ws_depth = depth;
+    return RT_OK;
+}
+
+int grow_shadow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
+    if (paths <= db.shadow_paths && depth <= db.shadow_depth) return RT_OK;
+    for (void *p : db.shadow_allocs) (void)hipFree(p);
+    db.shadow_allocs.clear();
+    db.shadow_paths = db.shadow_depth = 0;
+    auto take = [&](size_t bytes, void **out) -> int {
+        HIP_TRY(hipMalloc(out, bytes));
+        db.shadow_allocs.push_back(*out);
+        return RT_OK;
+    };
+    int rc;
+    const uint32_t chunks = (paths + 63) / 64;
+    const uint32_t cap = (chunks + rt::kShards - 1) / rt::kShards * 64; // as the bounce queues'
+    const size_t entries = (size_t)cap * rt::kShards;
+    if ((rc = take(entries * sizeof(float4), (void **)&db.shadow.a))) return rc;
+    if ((rc = take(entries * sizeof(float4), (void **)&db.shadow.b))) return rc;
+    if ((rc = take(entries * sizeof(float4), (void **)&db.shadow.c))) return rc;
+    db.shadow.cap = cap;
+    if ((rc = take(count_words(depth) * sizeof(uint32_t), (void **)&db.shadow_counts))) return rc;
+    db.shadow_paths = paths;
+    db.shadow_depth = depth;
     return RT_OK;
 }
 
@@ -1264,6 +1314,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     if (batch_paths64 >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard too large for one sample per batch");
     const uint32_t batch_paths = (uint32_t)batch_paths64;
     if ((rc = grow_workspace(*db, batch_paths ? batch_paths : 1, o->max_depth)) != RT_OK) return rc;
+    // direct lighting: one launch per bounce, each followed by the any-hit launch of its shadow rays
+    const bool direct = (o->flags & RT_RENDER_DIRECT_LIGHT) && db->dev.n_lights != 0;
+    if (direct && (rc = grow_shadow_workspace(*db, batch_paths ? batch_paths : 1, o->max_depth)) != RT_OK) return rc;
 
     // Once few rays are left one launch follows them to the end of their paths
     // (launch_bounce_loop): a launch per bounce is the better deal for full queues (less state
@@ -1297,15 +1350,16 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     HIP_TRY(hipEventRecord(ev_begin, st));
     // the sampler's tables or per-pixel samples belong to the frame's time
     if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) return rc;
-    uint64_t segments = 0, paths = 0, launches = 0;
+    uint64_t segments = 0, paths = 0, launches = 0, occlusion = 0;
     uint32_t batches = 0, max_bounce = 0;
-    std::vector<uint32_t> counts(count_words(o->max_depth));
+    std::vector<uint32_t> counts(count_words(o->max_depth)), scounts(direct ? count_words(o->max_depth) : 0);
     std::vector<uint64_t> per_bounce(o->max_depth, 0);
     for (uint32_t s0 = 0; s0 < o->spp && n_ranks; s0 += s_batch, batches++) {
         const uint32_t sc = std::min(s_batch, o->spp - s0);
         const uint32_t n_local = n_ranks * sc;
         HIP_TRY(hipMemsetAsync(db->counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(db->radiance, 0, (size_t)n_local * sizeof(float4), st));
+        if (direct) HIP_TRY(hipMemsetAsync(db->shadow_counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
         HIP_TRY(rt::launch_generate(F, *cam, db->q[0], db->counts, n_local, s0, sc, st));
         for (uint32_t b = 0; b < o->max_depth; b++) {
             if (want_timing) {
@@ -1316,8 +1370,8 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 ev.push_back(e0);
                 ev.push_back(e1);
             }
-            bool rest = b >= loop_from && b + 1 < o->max_depth;
-            if (!rest && loop_below && b >= 2 && (b & (b - 1)) == 0 && b + 1 < o->max_depth) {
+            bool rest = !direct && b >= loop_from && b + 1 < o->max_depth;
+            if (!direct && !rest && loop_below && b >= 2 && (b & (b - 1)) == 0 && b + 1 < o->max_depth) {
                 uint32_t sizes[rt::kShards * rt::kCountStride];
                 HIP_TRY(hipMemcpyAsync(sizes, db->counts + (size_t)b * rt::kShards * rt::kCountStride, sizeof sizes,
                                        hipMemcpyDeviceToHost, st));
@@ -1333,7 +1387,10 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             else
                 HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
                                           db->counts, b, o->max_depth - 1, o->seed, db->radiance,
-                                          db->bounce_scratch, want_counters ? db->counters : nullptr, st));
+                                          db->bounce_scratch, want_counters ? db->counters : nullptr, st,
+                                          direct ? &db->shadow : nullptr, db->shadow_counts));
+            if (direct)
+                HIP_TRY(rt::launch_shadow(db->dev, db->shape, db->shadow, db->shadow_counts, b, db->radiance, st));
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
             launches++;
             if (rest) break;
@@ -1349,6 +1406,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         // queue sizes of this batch = ray segments traced per bounce
         HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, counts.size() * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
+        if (direct)
+            HIP_TRY(hipMemcpyAsync(scounts.data(), db->shadow_counts, scounts.size() * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (counts[rt::kLoopErrorWord])
             return fail(RT_ERR_LIMIT, "a wave of the path kernel exceeded %u feed turns and dropped its segments: "
@@ -1362,6 +1422,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             per_bounce[b] += q;
             segments += q;
             if (q && b > max_bounce) max_bounce = b;
+            if (direct)
+                for (uint32_t k = 0; k < rt::kShards; k++)
+                    occlusion += scounts[((size_t)b * rt::kShards + k) * rt::kCountStride];
         }
     }
     HIP_TRY(hipEventRecord(ev_end, st));
@@ -1369,7 +1432,8 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->paths = paths;
-        stats->segments = segments;
+        stats->segments = segments + occlusion;
+        stats->occlusion_rays = occlusion;
         stats->trace_launches = launches;
         stats->batches = batches;
         stats->max_bounce = max_bounce;

@@ -50,6 +50,16 @@ struct Medium { // 16 B
     float neg_inv_density; // -1.0f / density, divided on the host
 };
 
+// A light of RT_RENDER_DIRECT_LIGHT: a rectangle without instance transform whose material is
+// a DiffuseLight with a solid colour.  scale = area * n_lights / pi (fp32, in that order).
+struct LightDev { // 48 B
+    uint32_t axis;
+    float k, a0, a1, b0, b1;
+    float scale;
+    float rgb[3];
+    uint32_t _pad[2];
+};
+
 struct ImageDev {
     const uint8_t *rgb8;
     uint32_t w, h;
@@ -77,6 +87,8 @@ struct SceneDev {
     const ImageDev *images;
     const float *perlin_vec;
     const int32_t *perlin_perm;
+    const LightDev *lights;
+    uint32_t n_lights;
     uint32_t n_nodes, n_prims; // n_nodes: LinearBVHNode count of the tree (0 = empty tree)
     // Media that enclose the scene are not in the tree: their entries follow the tree's
     // n_tree_prims primitives in `leaf`, and every ray tests them before it starts traversing.

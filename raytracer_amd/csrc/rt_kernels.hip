@@ -1232,11 +1232,31 @@ RT_DEV v3 texture_plain(const SceneDev &S, uint32_t tex, v3 p) {
 // four common surface kinds and media, the four materials and the two texture forms that
 // flag leaves out can occur; the general code is the same computation with every
 // case present.
-template <bool PLAIN>
-RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local, float4 *radiance) {
+// Direct lighting (NEE): what a hit on a Lambertian surface hands to the any-hit traversal.
+struct Shadow {
+    bool want;    // a shadow ray was made
+    bool sampled; // this vertex sampled the lights: the next one must not add a light's emission
+    v3 o, d, contrib;
+};
+constexpr float kShadowTMax = 1.0f - 0.0001f; // Interaction::spawn_ray_to, interaction.rs:113
+
+// The end of a path stores its radiance; with direct lighting the shadow rays of earlier
+// vertices have already added theirs.
+template <bool NEE>
+RT_DEV void add_radiance(float4 *radiance, uint32_t local, v3 v) {
+    if (NEE) {
+        float4 r = radiance[local];
+        radiance[local] = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, 0.0f);
+    } else {
+        radiance[local] = make_float4(v.x, v.y, v.z, 0.0f);
+    }
+}
+
+template <bool PLAIN, bool NEE = false>
+RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local, float4 *radiance,
+                  bool skip_emission = false, Shadow *sh = nullptr) {
     if (L.best == RT_MISS) {
-        radiance[local] =
-            make_float4(beta.x * S.background[0], beta.y * S.background[1], beta.z * S.background[2], 0.0f);
+        add_radiance<NEE>(radiance, local, mk(beta.x * S.background[0], beta.y * S.background[1], beta.z * S.background[2]));
         return false;
     }
     bool alive = true;
@@ -1269,8 +1289,32 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
         else tex = texture_value(S, m.texture, h.u, h.v, h.p);
     }
     v3 dir = nf;
+    if (NEE && m.kind == RT_MAT_LAMBERTIAN && S.n_lights) {
+        // one point on one light; the draws follow the scatter direction's
+        uint32_t li = 0;
+        if (S.n_lights > 1) {
+            li = (uint32_t)(rng_f(rng) * (float)S.n_lights);
+            if (li >= S.n_lights) li = S.n_lights - 1;
+        }
+        const float u1 = rng_f(rng), u2 = rng_f(rng);
+        const LightDev lt = S.lights[li];
+        const float qa = lt.a0 + u1 * (lt.a1 - lt.a0), qb = lt.b0 + u2 * (lt.b1 - lt.b0);
+        const v3 q = lt.axis == 0 ? mk(lt.k, qa, qb) : (lt.axis == 1 ? mk(qa, lt.k, qb) : mk(qa, qb, lt.k));
+        // Interaction::spawn_ray_to, shapes/src/interaction.rs:102-116
+        const v3 so = offset_origin(h.p, h.perr, h.n, q - h.p);
+        const v3 sd = q - so;
+        const float d2 = dot(sd, sd), cs = dot(sd, nf), cl = fabsf(comp(sd, (int)lt.axis));
+        if (cs > 0.0f && cl > 0.0f && d2 > 0.0f) {
+            const float g = (cs * cl) / (d2 * d2) * lt.scale;
+            sh->want = true;
+            sh->o = so;
+            sh->d = sd;
+            sh->contrib = mk(beta.x * tex.x * lt.rgb[0] * g, beta.y * tex.y * lt.rgb[1] * g, beta.z * tex.z * lt.rgb[2] * g);
+        }
+        sh->sampled = true;
+    }
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
-        radiance[local] = make_float4(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z, 0.0f);
+        if (!(NEE && skip_emission)) add_radiance<NEE>(radiance, local, mk(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z));
         alive = false;
     } else if (m.kind == RT_MAT_LAMBERTIAN) {
         dir = nf + rs;
@@ -1325,6 +1369,7 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
 // rather than whenever one ray of a wave does.  The lanes' traversal state is
 // written to memory around a shading batch and read back after it, so shading and
 // traversal do not compete for registers.
+template <bool NEE>
 struct BounceFeed {
     const SceneDev &S;
     const Queue &qin, &qout;
@@ -1339,6 +1384,9 @@ struct BounceFeed {
     uint32_t *save;     // kSaveWords x 64, word k of lane l at save[k * 64 + l]
     uint32_t parked[2]; // wave uniform
     uint32_t entry;     // queue entry of the ray this lane is tracing
+    // direct lighting: the shadow rays this bounce makes (sub-queue and tail as for qout)
+    ShadowQueue sq;
+    uint32_t *stail;
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     RT_DEV bool more() const { return blocks.more(); }
 
@@ -1353,6 +1401,21 @@ struct BounceFeed {
             if (alive) queue_push(qout, out_base + base + lane_rank(mask), P.ray, local, beta, rng, gpath);
         }
     }
+    RT_DEV void compact_shadow(const Shadow &sh, float time, uint32_t local) {
+        const uint64_t mask = __ballot(sh.want);
+        const uint32_t total = (uint32_t)__popcll(mask);
+        if (total) {
+            uint32_t base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(stail, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (sh.want) {
+                const size_t slot = out_base + base + lane_rank(mask); // same sub-queue geometry as qout
+                sq.a[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, time);
+                sq.b[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, __uint_as_float(local));
+                sq.c[slot] = make_float4(sh.contrib.x, sh.contrib.y, sh.contrib.z, 0.0f);
+            }
+        }
+    }
 
     template <bool PLAIN>
     RT_DEV void shade_batch(uint32_t first, uint32_t count) {
@@ -1362,6 +1425,9 @@ struct BounceFeed {
         v3 beta = mk(0.0f, 0.0f, 0.0f);
         Rng rng{0, 0};
         uint32_t gpath = 0, local = kDead;
+        Shadow sh;
+        sh.want = sh.sampled = false;
+        sh.o = sh.d = sh.contrib = mk(0.0f, 0.0f, 0.0f);
         if (lane < count) {
             const float4 ra = park_a[first + lane];
             const float2 rb = park_b[first + lane];
@@ -1395,9 +1461,17 @@ struct BounceFeed {
                 asm volatile("" ::"v"(sink));
             }
 #endif
-            alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && !last;
+            if (NEE) {
+                // bit 31 of the path index: the vertex before this one sampled the lights
+                const bool skip_emission = (local >> 31) != 0;
+                local &= 0x7fffffffu;
+                alive = shade<PLAIN, true>(S, P, beta, rng, local, radiance, skip_emission, &sh) && !last;
+            } else {
+                alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && !last;
+            }
         }
-        compact(alive, P, local, beta, rng, gpath);
+        if (NEE) compact_shadow(sh, P.ray.time, local);
+        compact(alive, P, NEE && sh.sampled ? (local | 0x80000000u) : local, beta, rng, gpath);
     }
 
     RT_DEV bool turn(Trav &T, bool free) {
@@ -1511,10 +1585,10 @@ struct BounceFeed {
 // path ends on a light or leaves the scene.  The launch must have a wave count
 // that is a multiple of kShards, so that wave w reads and writes sub-queue
 // shard_of_wave(w) only.
-template <bool COUNT, bool LDSN>
+template <bool COUNT, bool LDSN, bool NEE>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_bounce(
     SceneDev S, Queue qin, Queue qout, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
-    float4 *radiance, uint8_t *scratch, unsigned long long *counters) {
+    float4 *radiance, uint8_t *scratch, unsigned long long *counters, ShadowQueue sq, uint32_t *scounts) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
     uint32_t *cout = counts + (size_t)(bounce + 1) * kShards * kCountStride;
@@ -1529,19 +1603,79 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     const uint32_t w = wave_index(), shard = shard_of_wave(w), per_shard = wave_total() / kShards;
     const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
     uint8_t *mine = scratch + (size_t)w * kWaveScratchBytes;
-    BounceFeed feed{S, qin, qout, cout + shard * kCountStride, (size_t)shard * qin.cap, (size_t)shard * qout.cap,
+    BounceFeed<NEE> feed{S, qin, qout, cout + shard * kCountStride, (size_t)shard * qin.cap, (size_t)shard * qout.cap,
                     // blocks after a wave's first are claimed from the word next to the sub-queue's
                     // size (zero at launch: counts are cleared once per batch)
                     Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
                            counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
                     bounce == last, seed, radiance,
                     reinterpret_cast<float4 *>(mine), reinterpret_cast<float2 *>(mine + 2 * kParkSlots * 16),
-                    reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u};
+                    reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u, sq,
+                    NEE ? scounts + ((size_t)bounce * kShards + shard) * kCountStride : nullptr};
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
     PROF(cnt.p[7] = feed.prof_shade;)
     if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---- shadow rays (direct lighting) ----------------------------------------------------------------------
+// The rays Interaction::spawn_ray_to made during one bounce, through the any-hit traversal
+// (<BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863).  A ray that reaches its
+// light adds its contribution to its path's radiance; a path has at most one shadow ray per
+// bounce, so no two lanes touch the same slot.
+struct ShadowFeed {
+    const ShadowQueue &q;
+    size_t base;
+    Blocks blocks;
+    float4 *radiance;
+    uint32_t idx;
+    RT_DEV bool more() const { return blocks.more(); }
+    RT_DEV bool turn(Trav &T, bool free) {
+        Lane &L = T.L;
+        if (free && L.has_ray && L.best == RT_MISS) {
+            const float4 c = q.c[base + idx];
+            const uint32_t local = __float_as_uint(q.b[base + idx].w);
+            const float4 r = radiance[local];
+            radiance[local] = make_float4(r.x + c.x, r.y + c.y, r.z + c.z, 0.0f);
+        }
+        const uint32_t next = blocks.take(free);
+        if (free) {
+            idx = next;
+            L.has_ray = next != kNone;
+            if (L.has_ray) {
+                const float4 a = q.a[base + next], b = q.b[base + next];
+                L.ray.o = mk(a.x, a.y, a.z);
+                L.ray.time = a.w;
+                L.ray.d = mk(b.x, b.y, b.z);
+                L.ray.t_max = kShadowTMax;
+            }
+        }
+        return free && L.has_ray;
+    }
+    RT_DEV bool drain() { return false; }
+    RT_DEV void finish() {}
+};
+
+template <bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_shadow(
+    SceneDev S, ShadowQueue q, uint32_t *scounts, uint32_t bounce, float4 *radiance) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t *cin = scounts + (size_t)bounce * kShards * kCountStride;
+    const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
+    uint32_t longest = my_count;
+    for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
+    const uint32_t n_chunks = kShards * ((longest + 63) / 64);
+    if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
+    Counters cnt = {};
+    const uint32_t w = wave_index(), shard = shard_of_wave(w), per_shard = wave_total() / kShards;
+    const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
+    ShadowFeed feed{q, (size_t)shard * q.cap,
+                    Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
+                           scounts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
+                    radiance, kNone};
+    trace_stream<true, false, LDSN>(S, tv, feed, cnt);
 }
 
 // ---- the rest of the path in one launch ------------------------------------------------------------
@@ -2074,12 +2208,12 @@ hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue 
 
 hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu) {
     int n[4] = {0, 0, 0, 0};
-    hipError_t e = allow_lds(k_bounce<false, false>, lds_bytes);
-    if (e == hipSuccess) e = allow_lds(k_bounce<true, false>, lds_bytes);
+    hipError_t e = allow_lds(k_bounce<false, false, false>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_bounce<true, false, false>, lds_bytes);
     if (e == hipSuccess) e = allow_lds(k_intersect<false, false>, lds_bytes);
     if (e == hipSuccess) e = allow_lds(k_occluded<false>, lds_bytes);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], k_bounce<false, false>, kBlock, lds_bytes);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], k_bounce<true, false>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], k_bounce<false, false, false>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], k_bounce<true, false, false>, kBlock, lds_bytes);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], k_intersect<false, false>, kBlock, lds_bytes);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], k_occluded<false>, kBlock, lds_bytes);
     if (e != hipSuccess) return e;
@@ -2093,24 +2227,41 @@ uint32_t bounce_waves(const LaunchShape &L) { return L.grid * ((L.lds_nodes ? 10
 
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
-                         uint8_t *scratch, unsigned long long *counters, hipStream_t stream) {
+                         uint8_t *scratch, unsigned long long *counters, hipStream_t stream,
+                         const ShadowQueue *shadow, uint32_t *shadow_counts) {
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
-    if (L.lds_nodes) {
-        if (counters)
-            RT_LAUNCH((k_bounce<true, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      scratch, counters);
-        else
-            RT_LAUNCH((k_bounce<false, true>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      scratch, counters);
+    const ShadowQueue sq = shadow ? *shadow : ShadowQueue{nullptr, nullptr, nullptr, 0u};
+#define RT_BOUNCE(C, N, E)                                                                              \
+    RT_LAUNCH((k_bounce<C, N, E>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance, \
+              scratch, counters, sq, shadow_counts)
+    if (shadow) {
+        if (L.lds_nodes) {
+            if (counters) RT_BOUNCE(true, true, true);
+            else RT_BOUNCE(false, true, true);
+        } else {
+            if (counters) RT_BOUNCE(true, false, true);
+            else RT_BOUNCE(false, false, true);
+        }
     } else {
-        if (counters)
-            RT_LAUNCH((k_bounce<true, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      scratch, counters);
-        else
-            RT_LAUNCH((k_bounce<false, false>), L.grid, threads, S, qin, qout, counts, bounce, last, seed, radiance,
-                      scratch, counters);
+        if (L.lds_nodes) {
+            if (counters) RT_BOUNCE(true, true, false);
+            else RT_BOUNCE(false, true, false);
+        } else {
+            if (counters) RT_BOUNCE(true, false, false);
+            else RT_BOUNCE(false, false, false);
+        }
     }
+#undef RT_BOUNCE
+    return hipGetLastError();
+}
+
+hipError_t launch_shadow(const SceneDev &S, const LaunchShape &L, const ShadowQueue &q, uint32_t *shadow_counts,
+                         uint32_t bounce, float4 *radiance, hipStream_t stream) {
+    const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
+    const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
+    if (L.lds_nodes) RT_LAUNCH((k_shadow<true>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
+    else RT_LAUNCH((k_shadow<false>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
     return hipGetLastError();
 }
 

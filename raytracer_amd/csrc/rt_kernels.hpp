@@ -29,6 +29,16 @@ struct Queue {
     uint32_t cap;
 };
 
+// Shadow rays of one bounce (RT_RENDER_DIRECT_LIGHT), sub-queues as in Queue: the ray
+// Interaction::spawn_ray_to made (t_max = 1 - 0.0001 for all of them), the path's slot and
+// what the path gains if the ray reaches the light.
+struct ShadowQueue {
+    float4 *a; // origin.xyz, time
+    float4 *b; // direction.xyz (not normalised), local path index (bits)
+    float4 *c; // contribution.rgb, -
+    uint32_t cap;
+};
+
 // Halton::new (colour/src/samplers/halton.rs:25-52) for one frame size, plus the digit
 // permutations of the primes 5, 7 and 11 (data/src/lib.rs:16-41) that dimensions 2-4 use.
 struct HaltonDev {
@@ -127,9 +137,17 @@ hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu);
 constexpr size_t kWaveLoopBytes = 2 * kParkSlots * 5 * 16 + 64 * 2 * 16 + 512 * 4 * 16 + kSaveWords * 64 * 4;
 // waves of the bounce grid (scratch must hold max(kWaveScratchBytes, kWaveLoopBytes) for each)
 uint32_t bounce_waves(const LaunchShape &L);
+// shadow != null: direct lighting -- hits on Lambertian surfaces also append a shadow ray to
+// *shadow (tails at shadow_counts, laid out like counts), radiance is accumulated instead of
+// stored, and bit 31 of a queue entry's path index says that the vertex before sampled the lights.
 hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
-                         uint8_t *scratch, unsigned long long *counters, hipStream_t stream);
+                         uint8_t *scratch, unsigned long long *counters, hipStream_t stream,
+                         const ShadowQueue *shadow = nullptr, uint32_t *shadow_counts = nullptr);
+// The shadow rays bounce `bounce` made, through the any-hit traversal (BVH::does_intersect,
+// bvh.rs:801-863); an unoccluded ray adds its contribution to its path's radiance.
+hipError_t launch_shadow(const SceneDev &S, const LaunchShape &L, const ShadowQueue &q, uint32_t *shadow_counts,
+                         uint32_t bounce, float4 *radiance, hipStream_t stream);
 // Bounce `bounce` and all later ones of the paths queued in qin (sizes at
 // counts[(bounce * kShards + s) * kCountStride]); writes the number of segments traced at each
 // later bounce where launch_bounce would have left its queue sizes.

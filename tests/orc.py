@@ -55,6 +55,7 @@ def lib():
         L.orc_math_eval.restype = C.c_float
         L.orc_math_eval.argtypes = [i32, C.c_float, C.c_float]
         L.orc_offset_ray_origin.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_spawn_ray_to_test.argtypes = [vp, vp, vp, vp, C.c_float, vp]
         _LIB = L
     return _LIB
 
@@ -165,6 +166,15 @@ class OracleScene:
         _check(lib().orc_path_radiance(self.h, C.byref(cam), C.byref(opts), first, n,
                                        rgb.ctypes.data, seg.ctypes.data))
         return rgb, seg
+
+
+def spawn_ray_to(p, err, n, target, time=0.0):
+    """Interaction::spawn_ray_to (interaction.rs:102-116) -> one abi.ray_dtype record."""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (p, err, n, target)]
+    out = np.zeros(1, dtype=abi.ray_dtype)
+    lib().orc_spawn_ray_to_test(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                C.c_float(time), out.ctypes.data)
+    return out[0]
 
 
 def generate_rays(cam, opts, first, n):
