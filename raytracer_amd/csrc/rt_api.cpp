@@ -105,6 +105,15 @@ struct DeviceBuffers {
     // run one after another, so they can share a word that is cleared in front of each
     std::mutex cursor_lock;
     std::map<hipStream_t, uint32_t *> cursors;
+    // Bounce at which the last batch of a frame of this shape handed over to the one-launch
+    // kernel: the next batch of such a frame switches there without asking the device
+    // (queue sizes at a given bounce differ by a few per cent between batches and frames of the
+    // same shape, and the threshold is not sharp).
+    struct LoopHint {
+        uint32_t width = 0, height = 0, paths = 0, depth = 0, shard_index = 0, shard_count = 0, bounce = 0;
+        uint64_t below = 0;
+        bool valid = false;
+    } loop_hint;
     // tables or per-pixel samples of the camera sampler (grown on demand)
     void *sampler_mem = nullptr;
     size_t sampler_bytes = 0;
@@ -1321,8 +1330,10 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     // Once few rays are left one launch follows them to the end of their paths
     // (launch_bounce_loop): a launch per bounce is the better deal for full queues (less state
     // per ray, rays of one depth shade together) and a floor of ~0.1 ms per bounce under the
-    // frame time for nearly empty ones.  The host looks at the queue size before bounces 2, 4,
-    // 8, 16, ... (one small synchronising copy each) and switches below `loop_below` rays.
+    // frame time for nearly empty ones.  The first batch of a frame shape looks at the queue size
+    // before bounces 2, 4, 8, 16, ... (one small synchronising copy each) and switches below
+    // `loop_below` rays; later batches and frames of the same shape switch at the bounce found
+    // then, with no round trip to the host in the middle of a frame.
     // RT355_LOOP_FROM=<bounce> fixes the bounce instead, RT355_LOOP_BELOW=<rays> the threshold
     // (0: never), for tests and experiments.
     uint32_t loop_from = 0xffffffffu;
@@ -1357,6 +1368,11 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     for (uint32_t s0 = 0; s0 < o->spp && n_ranks; s0 += s_batch, batches++) {
         const uint32_t sc = std::min(s_batch, o->spp - s0);
         const uint32_t n_local = n_ranks * sc;
+        DeviceBuffers::LoopHint &hint = db->loop_hint;
+        const bool hinted = hint.valid && hint.width == o->width && hint.height == o->height && hint.paths == n_local &&
+                            hint.depth == o->max_depth && hint.shard_index == o->shard_index &&
+                            hint.shard_count == shard_count && hint.below == loop_below;
+        uint32_t switched_at = 0xffffffffu;
         HIP_TRY(hipMemsetAsync(db->counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(db->radiance, 0, (size_t)n_local * sizeof(float4), st));
         if (direct) HIP_TRY(hipMemsetAsync(db->shadow_counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
@@ -1371,7 +1387,9 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 ev.push_back(e1);
             }
             bool rest = !direct && b >= loop_from && b + 1 < o->max_depth;
-            if (!direct && !rest && loop_below && b >= 2 && (b & (b - 1)) == 0 && b + 1 < o->max_depth) {
+            if (!direct && !rest && loop_below && hinted) {
+                rest = b >= hint.bounce && b + 1 < o->max_depth;
+            } else if (!direct && !rest && loop_below && b >= 2 && (b & (b - 1)) == 0 && b + 1 < o->max_depth) {
                 uint32_t sizes[rt::kShards * rt::kCountStride];
                 HIP_TRY(hipMemcpyAsync(sizes, db->counts + (size_t)b * rt::kShards * rt::kCountStride, sizeof sizes,
                                        hipMemcpyDeviceToHost, st));
@@ -1379,6 +1397,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 uint64_t queued = 0;
                 for (uint32_t k = 0; k < rt::kShards; k++) queued += sizes[k * rt::kCountStride];
                 rest = queued < loop_below;
+                if (rest) switched_at = b;
             }
             if (rest)
                 HIP_TRY(rt::launch_bounce_loop(db->dev, db->shape, db->q[b & 1], db->counts, b, o->max_depth - 1,
@@ -1394,6 +1413,11 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             if (want_timing) HIP_TRY(hipEventRecord(ev.back(), st));
             launches++;
             if (rest) break;
+        }
+        if (switched_at != 0xffffffffu) {
+            hint.width = o->width; hint.height = o->height; hint.paths = n_local; hint.depth = o->max_depth;
+            hint.shard_index = o->shard_index; hint.shard_count = shard_count; hint.bounce = switched_at;
+            hint.below = loop_below; hint.valid = true;
         }
         if (filtered) {
             HIP_TRY(rt::launch_film(F, film, db->radiance, s0, sc, reinterpret_cast<float4 *>(d_rgba), st));

@@ -336,6 +336,25 @@ def test_one_launch_kernel_shares_sub_queues(monkeypatch, scene_cache, nodes):
             assert st.segments == rst.segments and list(st.bounce_rays) == list(bst.bounce_rays)
 
 
+def test_switch_bounce_is_remembered_between_frames(scene_cache):
+    """The first frame of a shape asks the device for its queue sizes to decide where the
+    one-launch kernel takes over; later frames of that shape switch at the same bounce without
+    the round trips: same launches, same image, also after a frame of another shape."""
+    _, cam, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp = 160, 96, 3
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, 50, seed=8))
+    first, fst = g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=8))
+    other, _ = g.render(cam(96, 64), lib.render_opts(96, 64, spp, 50, seed=8))
+    again, ast = g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=8))
+    third, tst = g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=9))
+    assert first.tobytes() == again.tobytes() == ref.tobytes() and fst.segments == ast.segments == rst.segments
+    assert 1 < fst.trace_launches < 50
+    assert tst.trace_launches == fst.trace_launches  # the 160 x 96 shape's bounce, found by its first frame
+    ref9, _ = o.render(cam(w, h), orc.render_opts(w, h, spp, 50, seed=9))
+    assert third.tobytes() == ref9.tobytes()
+
+
 def test_spin_guard_of_the_one_launch_kernel_is_reported(monkeypatch, scene_cache):
     """A wave of the kernel that follows paths to their end gives up after a fixed number of
     feed turns and drops its segments; the call must then fail instead of returning the
