@@ -607,6 +607,9 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     D.n_prims = (uint32_t)leaf.size();
     D.n_tree_prims = (uint32_t)n_tree_prims;
     D.n_enclosing = (uint32_t)s.enclosing.size();
+    D.enclosing_rare = 0;
+    for (size_t e = 0; e < s.enclosing.size(); e++)
+        if (leaf[n_tree_prims + e].kind & rt::kRareShade) D.enclosing_rare |= 1u << e;
     D.n_pairs = n_pairs;
     D.root_ref = nodes.empty() ? 0u : ref_of(0);
     for (int c = 0; c < 3; c++) {
@@ -721,7 +724,7 @@ int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].a))) return rc;
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].b))) return rc;
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].c))) return rc;
-        if ((rc = take(entries * sizeof(uint2), (void **)&db.q[k].d))) return rc;
+        if ((rc = take(entries * sizeof(uint4), (void **)&db.q[k].d))) return rc;
         db.q[k].cap = cap;
     }
     if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.radiance))) return rc;
@@ -1376,7 +1379,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         HIP_TRY(hipMemsetAsync(db->counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(db->radiance, 0, (size_t)n_local * sizeof(float4), st));
         if (direct) HIP_TRY(hipMemsetAsync(db->shadow_counts, 0, count_words(o->max_depth) * sizeof(uint32_t), st));
-        HIP_TRY(rt::launch_generate(F, *cam, db->q[0], db->counts, n_local, s0, sc, st));
+        HIP_TRY(rt::launch_generate(db->dev, F, *cam, db->q[0], db->counts, n_local, s0, sc, st));
         for (uint32_t b = 0; b < o->max_depth; b++) {
             if (want_timing) {
                 hipEvent_t e0, e1;
@@ -1503,10 +1506,10 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             }
 #endif
 #ifdef RT_PROFILE
-            unsigned long long pr[12];
+            unsigned long long pr[16];
             HIP_TRY(hipMemcpy(pr, db->counters + 16, sizeof pr, hipMemcpyDeviceToHost));
             fprintf(stderr, "rt355 profile:");
-            for (int k = 0; k < 12; k++) fprintf(stderr, " %llu", pr[k]);
+            for (int k = 0; k < 16; k++) fprintf(stderr, " %llu", pr[k]);
             fprintf(stderr, "\n");
 #endif
         }

@@ -93,6 +93,7 @@ struct SceneDev {
     // Media that enclose the scene are not in the tree: their entries follow the tree's
     // n_tree_prims primitives in `leaf`, and every ray tests them before it starts traversing.
     uint32_t n_tree_prims, n_enclosing;
+    uint32_t enclosing_rare; // bit e: a scatter in enclosing medium e needs the general shader
     uint32_t n_pairs;          // interior records in `nodes`
     uint32_t root_ref;         // reference to the root (a leaf when the tree is a single node)
     uint32_t stack_lds;        // stack levels per lane kept in LDS; deeper entries use private memory

@@ -137,7 +137,9 @@ struct Counters {
     // leaf rounds (longest lane), 4 lanes x primitives tested, 5 cycles in interior steps,
     // 6 cycles in leaf rounds, 7 cycles in shading batches (part of 8), 8 cycles in feed turns,
     // 9 cycles in all, 10 feed turns, 11 rays
-    PROF(unsigned long long p[12];)
+    // 12 cycles of a feed turn after the feed returned (reciprocal direction, enclosing media, root box),
+    // 13 cycles in Blocks::take, 14 cycles waiting for the new rays' queue entries, 15 cycles parking
+    PROF(unsigned long long p[16];)
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -380,24 +382,29 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
             if (n_busy == 0 || (64u - n_busy >= refill_lanes && feed.more())) {
                 const bool fresh = feed.turn(T, !busy);
+                PROF(const unsigned long long t_fresh = __builtin_amdgcn_s_memtime();)
                 if (fresh) { // bvh.rs:741-762: reciprocal direction, then the root's own box
                     inv = mk(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
                     sp = 0;
-                    L.best = RT_MISS;
-                    // Media that enclose the scene are not in the tree: every ray tests them here,
-                    // where all the lanes that were just fed run the same code, instead of inside a
-                    // leaf round.  A hit shortens the ray before the traversal starts.
+                    // Media that enclose the scene are not in the tree: every ray tests them before it
+                    // starts traversing, and a hit shortens it.  A feed whose rays were tested by
+                    // their producer (Feed::kPretested) hands over the outcome in L.best / L.ray.t_max.
                     bool occluded = false;
-                    for (uint32_t e = 0; e < S.n_enclosing; e++) {
-                        const uint32_t slot = S.n_tree_prims + e;
-                        const LeafPrim lp = S.leaf[slot];
-                        if (COUNT) cnt.prims[RT_MEDIUM]++;
-                        float t;
-                        if (medium_test(S, lp, L.ray, inv, t)) {
-                            L.ray.t_max = t;
-                            L.best = slot | ((lp.kind & kRareShade) ? kBestRare : 0u);
-                            L.a0 = L.a1 = L.a2 = 0.0f;
-                            if (ANY) occluded = true;
+                    if constexpr (Feed::kPretested) {
+                        if (COUNT) cnt.prims[RT_MEDIUM] += S.n_enclosing;
+                    } else {
+                        L.best = RT_MISS;
+                        for (uint32_t e = 0; e < S.n_enclosing; e++) {
+                            const uint32_t slot = S.n_tree_prims + e;
+                            const LeafPrim lp = S.leaf[slot];
+                            if (COUNT) cnt.prims[RT_MEDIUM]++;
+                            float t;
+                            if (medium_test(S, lp, L.ray, inv, t)) {
+                                L.ray.t_max = t;
+                                L.best = slot | ((lp.kind & kRareShade) ? kBestRare : 0u);
+                                L.a0 = L.a1 = L.a2 = 0.0f;
+                                if (ANY) occluded = true;
+                            }
                         }
                     }
                     if (S.n_nodes && !occluded) {
@@ -415,6 +422,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                 PROF(if (COUNT) {
                     const unsigned long long t = __builtin_amdgcn_s_memtime();
                     cnt.p[8] += t - tp;
+                    cnt.p[12] += t - t_fresh;
                     cnt.p[10]++;
                     tp = t;
                 })
@@ -550,6 +558,31 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
     PROF(if (COUNT) cnt.p[9] += __builtin_amdgcn_s_memtime() - tp0;)
 }
 
+// The media that enclose the scene, tested by whoever makes a ray (camera rays, scattered
+// rays: all lanes of a full wave at once) instead of by the traversal that picks the ray up
+// later with a few lanes.  t_max: the ray's end after them; which: 0, or k when the ray
+// scatters in the k-th of them.  The same tests in the same order on the same ray as
+// trace_stream makes for rays that come without this.
+RT_DEV void enclosing_pretest(const SceneDev &S, const Ray &ray, float &t_max, uint32_t &which) {
+    Ray r = ray;
+    which = 0;
+    const v3 rd = mk(0.0f, 0.0f, 0.0f); // only boxes read the reciprocal direction; these are spheres
+    for (uint32_t e = 0; e < S.n_enclosing; e++) {
+        const LeafPrim lp = S.leaf[S.n_tree_prims + e];
+        float t;
+        if (medium_test(S, lp, r, rd, t)) {
+            r.t_max = t;
+            which = e + 1;
+        }
+    }
+    t_max = r.t_max;
+}
+// leaf slot (| kBestRare) of the k-th enclosing medium, or RT_MISS for 0
+RT_DEV uint32_t enclosing_best(const SceneDev &S, uint32_t which) {
+    if (which == 0) return RT_MISS;
+    return (S.n_tree_prims + which - 1) | (((S.enclosing_rare >> (which - 1)) & 1u) ? kBestRare : 0u);
+}
+
 RT_DEV Ray load_ray(const rt_ray *rays, size_t i) {
     const float4 *p = reinterpret_cast<const float4 *>(rays + i);
     float4 a = p[0], b = p[1];
@@ -571,7 +604,7 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
         for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[k], (unsigned long long)x);
     }
-    PROF(for (int k = 0; k < 12; k++) {
+    PROF(for (int k = 0; k < 16; k++) {
         unsigned long long x = c.p[k];
         const bool per_lane = k == 1 || k == 4 || k == 11;
         if (per_lane)
@@ -582,6 +615,7 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
 
 // rt_intersect: hit records out, rays in
 struct HitFeed {
+    static constexpr bool kPretested = false;
     const SceneDev &S;
     const rt_ray *rays;
     rt_hit *hits;
@@ -650,6 +684,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 
 // rt_occluded: one byte per ray out
 struct AnyFeed {
+    static constexpr bool kPretested = false;
     const rt_ray *rays;
     uint8_t *out;
     Blocks blocks;
@@ -1071,12 +1106,17 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(FrameDev F, rt_camera 
 }
 
 // ---- bounce queues ------------------------------------------------------------------------------
-RT_DEV void queue_push(const Queue &q, size_t slot, const Ray &r, uint32_t local, v3 beta, const Rng &rng,
-                       uint32_t gpath) {
+RT_DEV void queue_push(const SceneDev &S, const Queue &q, size_t slot, const Ray &r, uint32_t local, v3 beta,
+                       const Rng &rng, uint32_t gpath) {
+    float t_max;
+    uint32_t which;
+    Ray fresh = r;
+    fresh.t_max = kInf; // every queued ray starts unbounded
+    enclosing_pretest(S, fresh, t_max, which);
     q.a[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
     q.b[slot] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(local));
     q.c[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
-    q.d[slot] = make_uint2((uint32_t)(rng.state >> 32), gpath);
+    q.d[slot] = make_uint4((uint32_t)(rng.state >> 32), gpath, __float_as_uint(t_max), which);
 }
 
 // pixel owned by this shard of the frame with rank r: 32x32 tiles, tile t = shard_index + k * shard_count
@@ -1091,7 +1131,7 @@ RT_DEV bool rank_to_pixel(const FrameDev &F, uint32_t rank, uint32_t &px, uint32
 
 // Primary rays, written in place: path `local` goes to chunk local / 64, chunk c to
 // sub-queue c % kShards.  Pixels outside the image (partial edge tiles) leave a dead entry.
-__global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, Queue q, uint32_t *counts,
+__global__ __launch_bounds__(kBlock) void k_generate(SceneDev S, FrameDev F, rt_camera cam, Queue q, uint32_t *counts,
                                                      uint32_t n_local, uint32_t s0, uint32_t s_count) {
     const uint32_t local = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_chunks = (n_local + 63) / 64;
@@ -1115,7 +1155,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameDev F, rt_camera cam, 
         }
     }
     if (alive) {
-        queue_push(q, slot, ray, local, mk(1.0f, 1.0f, 1.0f), rng, gpath);
+        queue_push(S, q, slot, ray, local, mk(1.0f, 1.0f, 1.0f), rng, gpath);
     } else {
         q.b[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kDead));
     }
@@ -1371,6 +1411,7 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
 // traversal do not compete for registers.
 template <bool NEE>
 struct BounceFeed {
+    static constexpr bool kPretested = true;
     const SceneDev &S;
     const Queue &qin, &qout;
     uint32_t *tail; // tail counter of the sub-queue written
@@ -1388,6 +1429,7 @@ struct BounceFeed {
     ShadowQueue sq;
     uint32_t *stail;
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
+    PROF(unsigned long long prof_take = 0; unsigned long long prof_load = 0; unsigned long long prof_park = 0;)
     RT_DEV bool more() const { return blocks.more(); }
 
     RT_DEV void compact(bool alive, const Lane &P, uint32_t local, v3 beta, const Rng &rng, uint32_t gpath) {
@@ -1398,7 +1440,7 @@ struct BounceFeed {
             uint32_t base = 0;
             if ((threadIdx.x & 63) == 0) base = atomicAdd(tail, total);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (alive) queue_push(qout, out_base + base + lane_rank(mask), P.ray, local, beta, rng, gpath);
+            if (alive) queue_push(S, qout, out_base + base + lane_rank(mask), P.ray, local, beta, rng, gpath);
         }
     }
     RT_DEV void compact_shadow(const Shadow &sh, float time, uint32_t local) {
@@ -1433,7 +1475,7 @@ struct BounceFeed {
             const float2 rb = park_b[first + lane];
             const size_t e = in_base + __float_as_uint(ra.x);
             const float4 qa = qin.a[e], qb = qin.b[e], qc = qin.c[e];
-            const uint2 qd = qin.d[e];
+            const uint4 qd = qin.d[e];
             P.ray.o = mk(qa.x, qa.y, qa.z);
             P.ray.time = qa.w;
             P.ray.d = mk(qb.x, qb.y, qb.z);
@@ -1478,6 +1520,7 @@ struct BounceFeed {
         Lane &L = T.L;
         const uint32_t lane = threadIdx.x & 63;
         // park the finished rays
+        PROF(const unsigned long long prof_tp = __builtin_amdgcn_s_memtime();)
         const bool finished = free && L.has_ray;
         const bool general = L.best != RT_MISS && (L.best & kBestRare) != 0;
         const uint64_t m0 = __ballot(finished && !general), m1 = __ballot(finished && general);
@@ -1488,7 +1531,7 @@ struct BounceFeed {
         }
         parked[0] += (uint32_t)__popcll(m0);
         parked[1] += (uint32_t)__popcll(m1);
-        PROF(const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();)
+        PROF(const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(); prof_park += prof_t0 - prof_tp;)
         if (parked[0] >= 64 || parked[1] >= 64) {
             // The traversing lanes' state leaves the registers while a batch is shaded.  When no
             // lane is traversing (small scenes: the rays of a wave finish together) there is
@@ -1541,25 +1584,32 @@ struct BounceFeed {
                 entry = 0;
             }
         }
-        PROF(prof_shade += __builtin_amdgcn_s_memtime() - prof_t0;)
+        PROF(const unsigned long long prof_t1 = __builtin_amdgcn_s_memtime(); prof_shade += prof_t1 - prof_t0;)
         // next rays
         const uint32_t next = blocks.take(free);
+        PROF(const unsigned long long prof_t2 = __builtin_amdgcn_s_memtime(); prof_take += prof_t2 - prof_t1;)
         bool fresh = false;
         if (free) {
             L.has_ray = false;
             if (next != kNone) {
                 const float4 qa = qin.a[in_base + next], qb = qin.b[in_base + next];
+                const uint4 qd = qin.d[in_base + next];
+                PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
                 if (__float_as_uint(qb.w) != kDead) {
                     L.ray.o = mk(qa.x, qa.y, qa.z);
                     L.ray.time = qa.w;
                     L.ray.d = mk(qb.x, qb.y, qb.z);
-                    L.ray.t_max = kInf;
+                    // what the ray's producer found in the media that enclose the scene
+                    L.ray.t_max = __uint_as_float(qd.z);
+                    L.best = enclosing_best(S, qd.w);
+                    L.a0 = L.a1 = L.a2 = 0.0f;
                     entry = next;
                     L.has_ray = true;
                     fresh = true;
                 }
             }
         }
+        PROF(prof_load += __builtin_amdgcn_s_memtime() - prof_t2;)
         return fresh;
     }
 
@@ -1615,7 +1665,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
-    PROF(cnt.p[7] = feed.prof_shade;)
+    PROF(cnt.p[7] = feed.prof_shade; cnt.p[13] = feed.prof_take; cnt.p[14] = feed.prof_load; cnt.p[15] = feed.prof_park;)
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -1625,6 +1675,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 // light adds its contribution to its path's radiance; a path has at most one shadow ray per
 // bounce, so no two lanes touch the same slot.
 struct ShadowFeed {
+    static constexpr bool kPretested = false;
     const ShadowQueue &q;
     size_t base;
     Blocks blocks;
@@ -1701,6 +1752,7 @@ static_assert(kWaveLoopBytes == kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes
               "per-wave memory of the loop kernel");
 
 struct LoopFeed {
+    static constexpr bool kPretested = true;
     const SceneDev &S;
     const Queue &qin;
     size_t in_base;
@@ -1762,11 +1814,18 @@ struct LoopFeed {
         if (mask) {
             if (alive) {
                 float4 *e = ring + (size_t)((ring_head + ring_count + lane_rank(mask)) % kRingSlots) * 4;
+                // the new ray against the media that enclose the scene, here where the whole
+                // batch works: t_max after them, and which of them it scatters in
+                float t_max;
+                uint32_t which;
+                Ray fresh = P.ray;
+                fresh.t_max = kInf;
+                enclosing_pretest(S, fresh, t_max, which);
                 e[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
-                e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, __uint_as_float(local));
+                e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
                 e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
                 e[3] = make_float4(__uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float(gpath),
-                                   __uint_as_float(local), __uint_as_float(depth + 1));
+                                   __uint_as_float(local), __uint_as_float((depth + 1) | (which << 8)));
             }
             ring_count += (uint32_t)__popcll(mask);
             // segments per bounce, where the per-bounce kernels keep their queue sizes
@@ -1884,21 +1943,28 @@ struct LoopFeed {
             float4 qa, qb, qc;
             uint4 qd = make_uint4(0u, 0u, 0u, 0u);
             bool got = false;
+            float t0 = kInf;    // the producer's findings in the media that enclose the scene:
+            uint32_t which = 0; // t_max after them, and which of them the ray scatters in
             if (ring_lane) {
                 const float4 *e = ring + (size_t)((ring_head + rank) % kRingSlots) * 4;
                 qa = e[0];
                 qb = e[1];
                 qc = e[2];
                 const float4 d4 = e[3];
-                qd = make_uint4(__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w));
+                t0 = qb.w;
+                which = __float_as_uint(d4.w) >> 8;
+                qd = make_uint4(__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z),
+                                __float_as_uint(d4.w) & 0xffu);
                 got = true;
             } else if (next != kNone) {
                 qa = qin.a[in_base + next];
                 qb = qin.b[in_base + next];
                 if (__float_as_uint(qb.w) != kDead) {
                     qc = qin.c[in_base + next];
-                    const uint2 d2 = qin.d[in_base + next];
-                    qd = make_uint4(d2.x, d2.y, __float_as_uint(qb.w), bounce0);
+                    const uint4 d4 = qin.d[in_base + next];
+                    t0 = __uint_as_float(d4.z);
+                    which = d4.w;
+                    qd = make_uint4(d4.x, d4.y, __float_as_uint(qb.w), bounce0);
                     got = true;
                 }
             }
@@ -1906,7 +1972,9 @@ struct LoopFeed {
                 L.ray.o = mk(qa.x, qa.y, qa.z);
                 L.ray.time = qa.w;
                 L.ray.d = mk(qb.x, qb.y, qb.z);
-                L.ray.t_max = kInf;
+                L.ray.t_max = t0;
+                L.best = enclosing_best(S, which);
+                L.a0 = L.a1 = L.a2 = 0.0f;
                 lane_c[lane] = qc;
                 lane_d[lane] = qd;
                 L.has_ray = true;
@@ -2198,10 +2266,10 @@ hipError_t launch_generate_rays(const FrameDev &F, const rt_camera &cam, uint64_
     return hipGetLastError();
 }
 
-hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
+hipError_t launch_generate(const SceneDev &S, const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
                            uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream) {
     uint32_t padded = (n_local + 63) / 64 * 64;
-    hipLaunchKernelGGL(k_generate, dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, F, cam, q,
+    hipLaunchKernelGGL(k_generate, dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, F, cam, q,
                        counts, n_local, s0, s_count);
     return hipGetLastError();
 }

@@ -25,7 +25,9 @@ struct Queue {
     float4 *a; // origin.xyz, time
     float4 *b; // direction.xyz, local path index (bits); 0xFFFFFFFF marks a dead entry
     float4 *c; // throughput.rgb, rng state low word (bits)
-    uint2 *d;  // rng state high word, global path id
+    uint4 *d;  // rng state high word, global path id, and what the ray's producer found when it
+               // tested the media that enclose the scene: t_max after them (bits), and which of them
+               // the ray scatters in (0 = none, k = the k-th)
     uint32_t cap;
 };
 
@@ -122,7 +124,9 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
 // pixel samplers: F.pixel_samples holds the pixels first / spp ... (slot = pixel - first / spp)
 hipError_t launch_generate_rays(const FrameDev &F, const rt_camera &cam, uint64_t first, uint32_t n,
                                 rt_ray *rays, hipStream_t stream);
-hipError_t launch_generate(const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
+// S: the scene the rays will be traced in (camera rays are tested against the media that
+// enclose it as they are made)
+hipError_t launch_generate(const SceneDev &S, const FrameDev &F, const rt_camera &cam, const Queue &q, uint32_t *counts,
                            uint32_t n_local, uint32_t s0, uint32_t s_count, hipStream_t stream);
 // Per-wave memory of the bounce kernel: two lists of parked hit records (kParkSlots x 24
 // bytes each) and the lanes' traversal state while a shading batch runs (kSaveWords x 64
