@@ -724,7 +724,9 @@ int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].a))) return rc;
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].b))) return rc;
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].c))) return rc;
-        if ((rc = take(entries * sizeof(uint4), (void **)&db.q[k].d))) return rc;
+        if ((rc = take(entries * sizeof(uint2), (void **)&db.q[k].d))) return rc;
+        db.q[k].e = nullptr;
+        if (db.dev.n_enclosing && (rc = take(entries * sizeof(uint2), (void **)&db.q[k].e))) return rc;
         db.q[k].cap = cap;
     }
     if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.radiance))) return rc;

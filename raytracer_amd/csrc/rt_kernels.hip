@@ -1108,15 +1108,18 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(FrameDev F, rt_camera 
 // ---- bounce queues ------------------------------------------------------------------------------
 RT_DEV void queue_push(const SceneDev &S, const Queue &q, size_t slot, const Ray &r, uint32_t local, v3 beta,
                        const Rng &rng, uint32_t gpath) {
-    float t_max;
-    uint32_t which;
-    Ray fresh = r;
-    fresh.t_max = kInf; // every queued ray starts unbounded
-    enclosing_pretest(S, fresh, t_max, which);
+    if (S.n_enclosing) {
+        float t_max;
+        uint32_t which;
+        Ray fresh = r;
+        fresh.t_max = kInf; // every queued ray starts unbounded
+        enclosing_pretest(S, fresh, t_max, which);
+        q.e[slot] = make_uint2(__float_as_uint(t_max), which);
+    }
     q.a[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
     q.b[slot] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(local));
     q.c[slot] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
-    q.d[slot] = make_uint4((uint32_t)(rng.state >> 32), gpath, __float_as_uint(t_max), which);
+    q.d[slot] = make_uint2((uint32_t)(rng.state >> 32), gpath);
 }
 
 // pixel owned by this shard of the frame with rank r: 32x32 tiles, tile t = shard_index + k * shard_count
@@ -1475,7 +1478,7 @@ struct BounceFeed {
             const float2 rb = park_b[first + lane];
             const size_t e = in_base + __float_as_uint(ra.x);
             const float4 qa = qin.a[e], qb = qin.b[e], qc = qin.c[e];
-            const uint4 qd = qin.d[e];
+            const uint2 qd = qin.d[e];
             P.ray.o = mk(qa.x, qa.y, qa.z);
             P.ray.time = qa.w;
             P.ray.d = mk(qb.x, qb.y, qb.z);
@@ -1593,15 +1596,16 @@ struct BounceFeed {
             L.has_ray = false;
             if (next != kNone) {
                 const float4 qa = qin.a[in_base + next], qb = qin.b[in_base + next];
-                const uint4 qd = qin.d[in_base + next];
+                uint2 qe = make_uint2(__float_as_uint(kInf), 0u);
+                if (S.n_enclosing) qe = qin.e[in_base + next];
                 PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
                 if (__float_as_uint(qb.w) != kDead) {
                     L.ray.o = mk(qa.x, qa.y, qa.z);
                     L.ray.time = qa.w;
                     L.ray.d = mk(qb.x, qb.y, qb.z);
                     // what the ray's producer found in the media that enclose the scene
-                    L.ray.t_max = __uint_as_float(qd.z);
-                    L.best = enclosing_best(S, qd.w);
+                    L.ray.t_max = __uint_as_float(qe.x);
+                    L.best = enclosing_best(S, qe.y);
                     L.a0 = L.a1 = L.a2 = 0.0f;
                     entry = next;
                     L.has_ray = true;
@@ -1816,11 +1820,13 @@ struct LoopFeed {
                 float4 *e = ring + (size_t)((ring_head + ring_count + lane_rank(mask)) % kRingSlots) * 4;
                 // the new ray against the media that enclose the scene, here where the whole
                 // batch works: t_max after them, and which of them it scatters in
-                float t_max;
-                uint32_t which;
-                Ray fresh = P.ray;
-                fresh.t_max = kInf;
-                enclosing_pretest(S, fresh, t_max, which);
+                float t_max = kInf;
+                uint32_t which = 0;
+                if (S.n_enclosing) {
+                    Ray fresh = P.ray;
+                    fresh.t_max = kInf;
+                    enclosing_pretest(S, fresh, t_max, which);
+                }
                 e[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
                 e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
                 e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
@@ -1961,10 +1967,13 @@ struct LoopFeed {
                 qb = qin.b[in_base + next];
                 if (__float_as_uint(qb.w) != kDead) {
                     qc = qin.c[in_base + next];
-                    const uint4 d4 = qin.d[in_base + next];
-                    t0 = __uint_as_float(d4.z);
-                    which = d4.w;
-                    qd = make_uint4(d4.x, d4.y, __float_as_uint(qb.w), bounce0);
+                    const uint2 d2 = qin.d[in_base + next];
+                    if (S.n_enclosing) {
+                        const uint2 qe = qin.e[in_base + next];
+                        t0 = __uint_as_float(qe.x);
+                        which = qe.y;
+                    }
+                    qd = make_uint4(d2.x, d2.y, __float_as_uint(qb.w), bounce0);
                     got = true;
                 }
             }

@@ -25,9 +25,10 @@ struct Queue {
     float4 *a; // origin.xyz, time
     float4 *b; // direction.xyz, local path index (bits); 0xFFFFFFFF marks a dead entry
     float4 *c; // throughput.rgb, rng state low word (bits)
-    uint4 *d;  // rng state high word, global path id, and what the ray's producer found when it
-               // tested the media that enclose the scene: t_max after them (bits), and which of them
-               // the ray scatters in (0 = none, k = the k-th)
+    uint2 *d;  // rng state high word, global path id
+    uint2 *e;  // scenes with media that enclose them only: what the ray's producer found when it
+               // tested those media -- t_max after them (bits), and which of them the ray
+               // scatters in (0 = none, k = the k-th)
     uint32_t cap;
 };
 
