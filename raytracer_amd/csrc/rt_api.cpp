@@ -1318,7 +1318,21 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         uint32_t tx = t % F.tiles_x, ty = t / F.tiles_x;
         owned_pixels += std::min(32u, o->width - tx * 32) * std::min(32u, o->height - ty * 32);
     }
-    uint32_t max_paths = o->max_paths ? o->max_paths : (1u << 27);
+    // Paths in flight per batch.  The library's own choice is 2^27 (two queues of 64-72 bytes per
+    // path and 16 bytes of radiance: 20 GB, nothing on a 288 GB device), less where the device has
+    // less to give: at most half of what is free now plus what the workspace already holds.
+    uint32_t max_paths = o->max_paths;
+    if (!max_paths) {
+        max_paths = 1u << 27;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t per_path = 2 * (3 * sizeof(float4) + sizeof(uint2) + (db->dev.n_enclosing ? sizeof(uint2) : 0)) +
+                                    sizeof(float4) + ((o->flags & RT_RENDER_DIRECT_LIGHT) ? 3 * sizeof(float4) : 0);
+            const size_t held = (size_t)db->ws_paths * per_path;
+            const size_t fit = (free_b + held) / 2 / per_path;
+            if (fit < max_paths) max_paths = (uint32_t)std::max<size_t>(fit, 1u << 16);
+        }
+    }
     if (max_paths < 1024) max_paths = 1024;
     // samples per batch: as many as fit, all pixels of the shard in every batch
     uint32_t s_batch = n_ranks ? max_paths / n_ranks : 1;
