@@ -25,3 +25,6 @@ for P in "${PASSES[@]}"; do
   rc=$?; echo "pass $i rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 "$ROOT/$OUT/pass$i.log"; exit $rc; fi
 done
+python3 $ROOT/tools/summarize_pmc.py "$ROOT/$OUT" "k_bounce<false,k_bounce_loop<false" --current "$ROOT/$OUT/pmc_current.json" --spp 64 > "$ROOT/$OUT/pmc_summary.json"
+cp "$ROOT/$OUT"/trace/*/*kernel_stats.csv "$ROOT/$OUT/kernel_stats.csv" 2>/dev/null || true
+echo "summaries: $OUT/pmc_summary.json $OUT/pmc_current.json $OUT/kernel_stats.csv"

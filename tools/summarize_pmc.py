@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter CSVs per kernel and derives the ratios quoted in the
-design notes.  usage: summarize_pmc.py <dir> [kernel substrings, comma separated] [--traffic out.json]
+design notes.  usage: summarize_pmc.py <dir> [kernel substrings, comma separated] [--current out.json --spp N]
+
+--current writes the file bench.py reads its roofline.traffic and roofline.valu from: the counters
+per frame, stamped with a hash of the kernel sources they were measured on (bench.py ignores the
+file when the sources have changed since) and with the samples per pixel of the measured frame.
 
 HBM traffic per launch = (FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024) / dispatches:
 on gfx950 FETCH_SIZE tallies the 128-byte requests of a 16-B-per-lane streaming read
@@ -16,7 +20,9 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 root = args[0]
 match = args[1] if len(args) > 1 else "k_bounce<false,k_bounce_loop<false"  # comma separated substrings
 wanted = match.split(",")
-traffic_out = sys.argv[sys.argv.index("--traffic") + 1] if "--traffic" in sys.argv else None
+traffic_out = sys.argv[sys.argv.index("--current") + 1] if "--current" in sys.argv else None
+spp = int(sys.argv[sys.argv.index("--spp") + 1]) if "--spp" in sys.argv else 64
+args = [a for a in args if a != traffic_out and a != str(spp)]
 tot = collections.defaultdict(float)
 disp = collections.defaultdict(set)
 for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True)):
@@ -49,9 +55,26 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     d["write_bytes"] = c["WRITE_SIZE"] * 1024
     d["hbm_bytes_per_launch"] = (c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024) / max(n, 1)
     if traffic_out:
-        json.dump({"kernel": match, "launches": n, "fetch_KiB_raw": c["FETCH_SIZE"],
-                   "write_KiB": c["WRITE_SIZE"],
-                   "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane streaming reads); WRITE_SIZE exact",
-                   "hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"])}, open(traffic_out, "w"), indent=1)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        # Vector-instruction issue peak: tools/valu_peak.hip on the same chip sustains 2.5 cycles per
+        # wave64 instruction per SIMD for plain fp32 / integer / logic operations with two or more
+        # waves per SIMD (profiles/r02_valu_peak.jsonl: 930-970 G wave-instructions/s at the
+        # 2.3 GHz the chip holds under that load); v_max, v_mul_lo_u32 take 4.2, v_rcp 8.2.
+        cur = {"source_hash": bench.kernel_source_hash(), "spp": spp, "kernel": match, "launches_per_frame": n,
+               "fetch_KiB_raw": c["FETCH_SIZE"], "write_KiB": c["WRITE_SIZE"],
+               "correction": "FETCH_SIZE x2 (gfx950: 128-byte requests of 16-B-per-lane streaming reads are tallied "
+                             "at 64 bytes; an upper bound here, part of the reads are 16-byte gathers); WRITE_SIZE as is",
+               "hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]),
+               "source": "profiles/pmc_current.json (rocprofv3 --pmc passes of bench.py --steps 1 --warmup 0, tools/profile_round.sh)"}
+        if c.get("SQ_INSTS_VALU"):
+            cur["valu"] = {"wave_insts_per_frame": c["SQ_INSTS_VALU"], "salu_insts_per_frame": c.get("SQ_INSTS_SALU"),
+                           "peak_ginst_s": 950.0,
+                           "peak_basis": "256 CUs x 4 SIMDs x 2.3 GHz / 2.5 cycles per wave64 instruction, measured with "
+                                         "tools/valu_peak.hip (profiles/r02_valu_peak.jsonl)",
+                           "active_lane_frac": round(d.get("valu_active_lane_frac", 0.0), 4),
+                           "wait_any_frac": round(d.get("wait_any_frac", 0.0), 4)}
+        json.dump(cur, open(traffic_out, "w"), indent=1)
 out["derived"] = d
 print(json.dumps(out, indent=1))
