@@ -559,10 +559,32 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     }
     for (const rt_linear_node &n : nodes)
         if (n.primitive_count) leaf[n.child_offset + n.primitive_count - 1].kind |= rt::kLastInLeaf;
+    // material and texture of every hit the plain shader covers, beside its leaf entry
+    std::vector<rt::PlainShade> plain(leaf.size());
+    for (size_t k = 0; k < leaf.size(); k++) {
+        rt::PlainShade &ps = plain[k];
+        memset(&ps, 0, sizeof ps);
+        if ((leaf[k].kind & rt::kRareShade) || leaf[k].material >= s.materials.size()) continue;
+        const rt_material &m = s.materials[leaf[k].material];
+        ps.material_kind = m.kind;
+        ps.fuzz = m.fuzz;
+        ps.ior = m.ior;
+        if (m.kind == RT_MAT_DIELECTRIC || m.texture >= s.textures.size()) continue; // no texture read
+        const rt_texture &t = s.textures[m.texture];
+        if (t.kind == RT_TEX_CHECKER) {
+            ps.checker = 1;
+            ps.scale = t.scale;
+            memcpy(ps.a, s.textures[t.a].rgb, sizeof ps.a);
+            memcpy(ps.b, s.textures[t.b].rgb, sizeof ps.b);
+        } else {
+            memcpy(ps.a, t.rgb, sizeof ps.a);
+        }
+    }
     rt::SceneDev &D = db.dev;
     int rc;
     if ((rc = upload(db, dn, &D.nodes))) return rc;
     if ((rc = upload(db, leaf, &D.leaf))) return rc;
+    if ((rc = upload(db, plain, &D.plain))) return rc;
     if ((rc = upload(db, spheres, &D.spheres))) return rc;
     if ((rc = upload(db, msph, &D.msph))) return rc;
     if ((rc = upload(db, tris, &D.tris))) return rc;

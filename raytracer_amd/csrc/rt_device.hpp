@@ -60,6 +60,17 @@ struct LightDev { // 48 B
     uint32_t _pad[2];
 };
 
+// What the plain shader needs of a primitive's material and texture, per leaf slot, so that a
+// shading batch reads it beside the leaf entry instead of following leaf -> material -> texture
+// (-> checker cells) through three dependent loads.  Valid for leaf entries without kRareShade.
+struct PlainShade { // 48 B
+    uint32_t material_kind; // rt_material_kind
+    float fuzz, ior;
+    uint32_t checker;       // 0: solid colour a; 1: 3-D checker, a where the sines' product is negative, else b
+    float a[3], scale;
+    float b[3], _pad;
+};
+
 struct ImageDev {
     const uint8_t *rgb8;
     uint32_t w, h;
@@ -84,6 +95,7 @@ struct SceneDev {
     const Medium *media;
     const rt_material *materials;
     const rt_texture *textures;
+    const PlainShade *plain;  // n_prims, in leaf order
     const ImageDev *images;
     const float *perlin_vec;
     const int32_t *perlin_perm;

@@ -1259,16 +1259,6 @@ RT_DEV v3 offset_origin(v3 p, v3 err, v3 n, v3 w) {
     return po;
 }
 
-// Texture of a plain hit: a solid colour, or a 3-D checker whose two cells are solid colours.
-RT_DEV v3 texture_plain(const SceneDev &S, uint32_t tex, v3 p) {
-    rt_texture t = S.textures[tex];
-    if (t.kind == RT_TEX_CHECKER) {
-        float sines = p_sin(t.scale * p.x) * p_sin(t.scale * p.y) * p_sin(t.scale * p.z);
-        t = S.textures[sines < 0.0f ? t.a : t.b];
-    }
-    return mk(t.rgb[0], t.rgb[1], t.rgb[2]);
-}
-
 // Shading of one finished path segment: emit, or scatter into the next ray
 // (L.ray.o / L.ray.d) with the throughput updated.  Returns whether the path
 // continues.  PLAIN: the hit does not carry kBestRare (or is a miss), so only the
@@ -1310,7 +1300,19 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     const v3 d = L.ray.d;
     const bool front = dot(d, h.n) < 0.0f;
     const v3 nf = front ? h.n : -h.n;
-    const rt_material m = S.materials[lp.material];
+    // The plain shader reads material and texture from the record beside the leaf entry (one
+    // load that does not wait for the leaf entry); the general one follows the references.
+    rt_material m;
+    PlainShade ps;
+    if (PLAIN) {
+        ps = S.plain[L.best & ~kBestRare];
+        m.kind = ps.material_kind;
+        m.texture = 0;
+        m.fuzz = ps.fuzz;
+        m.ior = ps.ior;
+    } else {
+        m = S.materials[lp.material];
+    }
     // The pieces every material shares run once for the whole wave: the
     // texture lookup (all but dielectrics) and the unit-sphere sample
     // (Lambertian, metallic, isotropic).  Per path the RNG draws stay in
@@ -1328,8 +1330,15 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
         rs = random_in_unit_sphere(rng);
     if (m.kind != RT_MAT_DIELECTRIC) {
-        if (PLAIN) tex = texture_plain(S, m.texture, h.p);
-        else tex = texture_value(S, m.texture, h.u, h.v, h.p);
+        if (PLAIN) {
+            tex = mk(ps.a[0], ps.a[1], ps.a[2]);
+            if (ps.checker) { // a solid colour, or a 3-D checker whose two cells are solid colours
+                const float sines = p_sin(ps.scale * h.p.x) * p_sin(ps.scale * h.p.y) * p_sin(ps.scale * h.p.z);
+                if (!(sines < 0.0f)) tex = mk(ps.b[0], ps.b[1], ps.b[2]);
+            }
+        } else {
+            tex = texture_value(S, m.texture, h.u, h.v, h.p);
+        }
     }
     v3 dir = nf;
     if (NEE && m.kind == RT_MAT_LAMBERTIAN && S.n_lights) {
