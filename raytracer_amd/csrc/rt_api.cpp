@@ -559,19 +559,21 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     }
     for (const rt_linear_node &n : nodes)
         if (n.primitive_count) leaf[n.child_offset + n.primitive_count - 1].kind |= rt::kLastInLeaf;
-    // material and texture of every hit the plain shader covers, beside its leaf entry
-    std::vector<rt::PlainShade> plain(leaf.size());
-    for (size_t k = 0; k < leaf.size(); k++) {
+    // What the plain shader needs of every material, in one record: its kind and parameters and
+    // its texture when that is a solid colour or a checker of two solid colours (the hits of any
+    // other material go to the general shader, which follows the references).
+    std::vector<rt::PlainShade> plain(s.materials.size());
+    for (size_t k = 0; k < plain.size(); k++) {
         rt::PlainShade &ps = plain[k];
         memset(&ps, 0, sizeof ps);
-        if ((leaf[k].kind & rt::kRareShade) || leaf[k].material >= s.materials.size()) continue;
-        const rt_material &m = s.materials[leaf[k].material];
+        const rt_material &m = s.materials[k];
         ps.material_kind = m.kind;
         ps.fuzz = m.fuzz;
         ps.ior = m.ior;
         if (m.kind == RT_MAT_DIELECTRIC || m.texture >= s.textures.size()) continue; // no texture read
         const rt_texture &t = s.textures[m.texture];
         if (t.kind == RT_TEX_CHECKER) {
+            if (t.a >= s.textures.size() || t.b >= s.textures.size()) continue;
             ps.checker = 1;
             ps.scale = t.scale;
             memcpy(ps.a, s.textures[t.a].rgb, sizeof ps.a);

@@ -60,9 +60,11 @@ struct LightDev { // 48 B
     uint32_t _pad[2];
 };
 
-// What the plain shader needs of a primitive's material and texture, per leaf slot, so that a
-// shading batch reads it beside the leaf entry instead of following leaf -> material -> texture
-// (-> checker cells) through three dependent loads.  Valid for leaf entries without kRareShade.
+// What the plain shader needs of a material and its texture, one record per material, so that a
+// shading batch reads it in one load beside the geometry's instead of following material ->
+// texture (-> checker cells) through three dependent loads.  Meant for the hits of leaf entries
+// without kRareShade (a per-primitive table of the same records made the large scenes slower: a
+// 48-byte gather from a table as large as the primitives').
 struct PlainShade { // 48 B
     uint32_t material_kind; // rt_material_kind
     float fuzz, ior;
@@ -95,7 +97,7 @@ struct SceneDev {
     const Medium *media;
     const rt_material *materials;
     const rt_texture *textures;
-    const PlainShade *plain;  // n_prims, in leaf order
+    const PlainShade *plain;  // one per material
     const ImageDev *images;
     const float *perlin_vec;
     const int32_t *perlin_perm;

@@ -1300,12 +1300,12 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     const v3 d = L.ray.d;
     const bool front = dot(d, h.n) < 0.0f;
     const v3 nf = front ? h.n : -h.n;
-    // The plain shader reads material and texture from the record beside the leaf entry (one
-    // load that does not wait for the leaf entry); the general one follows the references.
+    // The plain shader reads material and texture from one record per material (a load that
+    // runs beside the geometry's); the general one follows the references.
     rt_material m;
     PlainShade ps;
     if (PLAIN) {
-        ps = S.plain[L.best & ~kBestRare];
+        ps = S.plain[lp.material];
         m.kind = ps.material_kind;
         m.texture = 0;
         m.fuzz = ps.fuzz;
