@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--checksum", action="store_true", help="print a checksum of the final frame to stderr")
+    ap.add_argument("--single-rank-collective", action="store_true",
+                    help="rehearsal only: a world of one still joins the process group and runs the frame's "
+                         "reduce, the barriers and the all-reduces through the backend (RCCL with one rank)")
     args = ap.parse_args()
 
     import torch
@@ -143,7 +146,8 @@ def main():
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.single_rank_collective
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -168,10 +172,10 @@ def main():
             opts = lib.render_opts(WIDTH, HEIGHT, args.spp, DEPTH, seed=0, shard=(index, count), flags=flags)
             return scene.render_dev(cam, opts, buf.data_ptr(), stream)
 
-        return render_frame(shard, fb, rank, world, dist)
+        return render_frame(shard, fb, rank, world, dist, single_rank_collective=args.single_rank_collective)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +200,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         t_max = tot[:1].clone()
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         seg_sum = tot[1:].clone()
@@ -238,7 +242,7 @@ def main():
                                  "instruction issue (see valu)"},
             "host": host_info(),
         }
-        # hardware counters of a rocprofv3 run on these very kernel sources (tools/collect_pmc.sh)
+        # hardware counters of a rocprofv3 run on these very kernel sources (tools/profile_round.sh)
         pmc_file = os.path.join(ROOT, "profiles", "pmc_current.json")
         if world == 1 and os.path.exists(pmc_file):
             with open(pmc_file) as f:
@@ -259,7 +263,7 @@ def main():
             out["cpu_baseline"] = cpu
             out["host"]["cpu_threads_used"] = cpu["cores"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

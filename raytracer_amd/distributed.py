@@ -21,7 +21,7 @@ def tiles_of(width, height, rank, world):
     return list(range(rank, tiles_x * tiles_y, world))
 
 
-def render_frame(render_shard, framebuffer, rank, world, dist=None, resolve=None):
+def render_frame(render_shard, framebuffer, rank, world, dist=None, resolve=None, single_rank_collective=False):
     """``render_shard(shard_index, shard_count, framebuffer)`` fills this rank's
     tiles (and zeroes the rest); with world > 1 the buffers are summed onto
     rank 0 through ``dist`` (torch.distributed, backend nccl = RCCL on GPUs,
@@ -30,9 +30,12 @@ def render_frame(render_shard, framebuffer, rank, world, dist=None, resolve=None
     With a reconstruction filter a sample also weighs on pixels of other ranks'
     tiles: ``render_shard`` must then leave a raw film (RT_RENDER_RAW_FILM:
     sums of w*L and of w, which add across ranks) and ``resolve(framebuffer)``
-    normalises the summed film on rank 0 (rt_film_resolve_dev)."""
+    normalises the summed film on rank 0 (rt_film_resolve_dev).
+
+    ``single_rank_collective`` runs the reduce through ``dist`` for a world of one as well (a
+    rehearsal of the collective's code path where only one device is at hand)."""
     out = render_shard(rank, world, framebuffer)
-    if world > 1:
+    if world > 1 or single_rank_collective:
         dist.reduce(framebuffer, dst=0, op=dist.ReduceOp.SUM)
     if resolve is not None and rank == 0:
         resolve(framebuffer)

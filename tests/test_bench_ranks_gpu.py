@@ -37,3 +37,17 @@ def test_two_ranks_equal_one_rank():
             assert key in line
         assert line["scaling"] == "strong" and line["vs_baseline"] is None
         assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl():
+    """The collectives of the N > 1 path (frame reduce, barriers, the two all-reduces) through the
+    nccl backend = RCCL itself, with the one rank a single-GPU box allows: the frame and the
+    segment count must be those of the plain single-process run."""
+    one, sha1 = run([sys.executable, "bench.py"] + COMMON)
+    rccl, sha2 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                      "--master-addr", "127.0.0.1", "--master-port", "29534", "bench.py", "--gpus", "1",
+                      "--single-rank-collective"] + COMMON)
+    assert sha1 == sha2
+    assert rccl["n_gpus"] == 1
+    assert rccl["config"]["ray_segments_per_frame"] == one["config"]["ray_segments_per_frame"]
