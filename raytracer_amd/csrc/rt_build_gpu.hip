@@ -1,7 +1,7 @@
 // rt_build_gpu.hip -- HLBVH construction on the GPU (hlbvh_build, shapes/src/bvh.rs:385-449):
-// Morton codes (:396-406, morton_encode3 :903-919), the radix sort (:923-966, here
-// rocPRIM's stable LSD sort: a stable sort on the 30-bit code has one possible result),
-// and the treelets (emit_lvbh :452-538).  Only the small SAH tree above the at most 4096
+// Morton codes (:396-406, morton_encode3 :903-919), the radix sort (:923-966: five stable
+// passes of six bits, least significant first -- 64 buckets, one per lane of a wave, see
+// k_sort_count / k_sort_scatter), and the treelets (emit_lvbh :452-538).  Only the small SAH tree above the at most 4096
 // treelets (build_upper_sah :541-658) runs on the host.  The output is the host builder's
 // tree node for node: boxes are unions (min / max, exact in any order), splits are found
 // with the same binary search, and node numbers are those of the pre-order flattening
@@ -17,8 +17,6 @@
 #include <string.h>
 
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 
@@ -63,6 +61,124 @@ __global__ void k_morton(const Aabb *bounds, uint32_t n, Aabb cb, uint32_t *code
     }
     codes[i] = (spread3(q[2]) << 2) | (spread3(q[1]) << 1) | spread3(q[0]);
     ids[i] = i;
+}
+
+// ---- radix_sort, bvh.rs:923-966: stable LSD passes of kRadixBits bits -------------------------
+// A pass sorts (code, id) pairs by one 6-bit digit and keeps the order of equal digits.  The 64
+// buckets of a pass are the 64 lanes of a wave: lane b keeps bucket b's counter.  A 256-thread
+// workgroup owns a tile of 4096 consecutive pairs, each of its four waves 1024 of them, which it
+// walks in 16 rounds of 64 consecutive pairs (lane l takes pair 64 r + l, so loads are
+// coalesced and lane order is input order).  In a round six ballots (one per digit bit) give
+// every lane two masks at once: the lanes whose digit equals its own (its rank among them is
+// the count of lower lanes in that mask) and the lanes whose digit equals its lane number (the
+// round's contribution to the bucket it keeps).  Pass = count per tile (and per bucket in all)
+// -> exclusive scan over (bucket, tile), one workgroup per bucket -> scatter; the scatter
+// repeats the count from registers to know where each wave of the tile starts inside every
+// bucket.
+constexpr int kRadixBits = 6, kSortPasses = 5; // bits_per_pass, n_passes, bvh.rs:924-926
+constexpr int kSortWaves = kThreads / 64, kSortRounds = 16;
+constexpr uint32_t kSortTile = kThreads * kSortRounds;
+
+__device__ inline void digit_masks(uint32_t digit, bool valid, uint32_t lane, uint64_t &same, uint64_t &kept) {
+    same = kept = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; b++) {
+        const uint64_t set = __ballot(valid && ((digit >> b) & 1u));
+        same &= ((digit >> b) & 1u) ? set : ~set;
+        kept &= ((lane >> b) & 1u) ? set : ~set;
+    }
+}
+
+// hist[bucket * n_tiles + tile] = pairs of the tile whose digit is `bucket`; totals[bucket] += the same
+__global__ __launch_bounds__(kThreads) void k_sort_count(const uint32_t *codes, uint32_t n, int shift, uint32_t *hist,
+                                                         uint32_t n_tiles, uint32_t *totals) {
+    __shared__ uint32_t wave_count[kSortWaves][64];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t first = (size_t)blockIdx.x * kSortTile + (size_t)w * 64 * kSortRounds;
+    uint32_t count = 0;
+    for (int r = 0; r < kSortRounds; r++) {
+        const size_t i = first + (size_t)r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t digit = valid ? (codes[i] >> shift) & 63u : 0u;
+        uint64_t same, kept;
+        digit_masks(digit, valid, lane, same, kept);
+        count += (uint32_t)__popcll(kept);
+    }
+    wave_count[w][lane] = count;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t total = 0;
+        for (int k = 0; k < kSortWaves; k++) total += wave_count[k][lane];
+        hist[(size_t)lane * n_tiles + blockIdx.x] = total;
+        if (total) atomicAdd(&totals[lane], total);
+    }
+}
+
+// Workgroup b turns row b of hist (bucket b, all tiles) into where each tile's pairs of that
+// bucket start: the pairs of lower buckets (from totals) plus the row's exclusive prefix sum.
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *hist, uint32_t n_tiles, const uint32_t *totals) {
+    __shared__ uint32_t part[1024];
+    uint32_t *v = hist + (size_t)blockIdx.x * n_tiles;
+    const uint32_t t = threadIdx.x, per = (n_tiles + 1023) / 1024;
+    const uint32_t lo = min(t * per, n_tiles), hi = min(lo + per, n_tiles);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += v[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t step = 1; step < 1024; step <<= 1) { // inclusive scan of the 1024 partial sums
+        const uint32_t add = t >= step ? part[t - step] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t k = 0; k < blockIdx.x; k++) run += totals[k];
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t x = v[i];
+        v[i] = run;
+        run += x;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_sort_scatter(const uint32_t *codes, const uint32_t *ids, uint32_t n, int shift,
+                                                           const uint32_t *offsets, uint32_t n_tiles, uint32_t *codes_out,
+                                                           uint32_t *ids_out) {
+    __shared__ uint32_t wave_count[kSortWaves][64];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t first = (size_t)blockIdx.x * kSortTile + (size_t)w * 64 * kSortRounds;
+    uint32_t code[kSortRounds], id[kSortRounds];
+    uint32_t count = 0;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; r++) {
+        const size_t i = first + (size_t)r * 64 + lane;
+        const bool valid = i < n;
+        code[r] = valid ? codes[i] : 0u;
+        id[r] = valid ? ids[i] : 0u;
+        uint64_t same, kept;
+        digit_masks((code[r] >> shift) & 63u, valid, lane, same, kept);
+        count += (uint32_t)__popcll(kept);
+    }
+    wave_count[w][lane] = count;
+    __syncthreads();
+    // where this wave's pairs of bucket `lane` go: after all pairs of lower buckets, of the bucket
+    // in earlier tiles, and in earlier waves of this tile
+    uint32_t next = offsets[(size_t)lane * n_tiles + blockIdx.x];
+    for (uint32_t k = 0; k < w; k++) next += wave_count[k][lane];
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; r++) {
+        const size_t i = first + (size_t)r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t digit = (code[r] >> shift) & 63u;
+        uint64_t same, kept;
+        digit_masks(digit, valid, lane, same, kept);
+        const uint32_t at = (uint32_t)__shfl((int)next, (int)digit, 64) + (uint32_t)__popcll(same & below);
+        if (valid) {
+            codes_out[at] = code[r];
+            ids_out[at] = id[r];
+        }
+        next += (uint32_t)__popcll(kept);
+    }
 }
 
 __global__ void k_roots(const uint32_t *starts, uint32_t n_treelets, GNode *nodes) {
@@ -258,11 +374,27 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
     hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_bounds, n, cb, d_codes, d_ids);
     GPU_TRY(hipGetLastError());
 
-    size_t temp_bytes = 0;
-    GPU_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_codes, d_codes2, d_ids, d_ids2, n, 0, 30));
-    char *d_temp;
-    GPU_TRY(mem.get(&d_temp, temp_bytes));
-    GPU_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_codes, d_codes2, d_ids, d_ids2, n, 0, 30));
+    // radix_sort, bvh.rs:923-966: an odd number of passes leaves the result in the second pair of buffers
+    {
+        const uint32_t n_tiles = (uint32_t)((n64 + kSortTile - 1) / kSortTile);
+        uint32_t *d_hist, *d_totals;
+        GPU_TRY(mem.get(&d_hist, (size_t)64 * n_tiles));
+        GPU_TRY(mem.get(&d_totals, (size_t)64 * kSortPasses));
+        GPU_TRY(hipMemset(d_totals, 0, sizeof(uint32_t) * 64 * kSortPasses));
+        uint32_t *in_c = d_codes, *in_i = d_ids, *out_c = d_codes2, *out_i = d_ids2;
+        for (int pass = 0; pass < kSortPasses; pass++) {
+            const int shift = pass * kRadixBits;
+            hipLaunchKernelGGL(k_sort_count, dim3(n_tiles), dim3(kThreads), 0, nullptr, in_c, n, shift, d_hist, n_tiles,
+                               d_totals + 64 * pass);
+            hipLaunchKernelGGL(k_sort_scan, dim3(64), dim3(1024), 0, nullptr, d_hist, n_tiles, d_totals + 64 * pass);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(kThreads), 0, nullptr, in_c, in_i, n, shift, d_hist,
+                               n_tiles, out_c, out_i);
+            std::swap(in_c, out_c);
+            std::swap(in_i, out_i);
+        }
+        GPU_TRY(hipGetLastError());
+        static_assert(kSortPasses % 2 == 1, "the sorted pairs are read from d_codes2 / d_ids2 below");
+    }
 
     // treelets: maximal runs with equal top 12 bits (bvh.rs:414-431)
     std::vector<uint32_t> codes(n);
