@@ -15,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_bvh.hpp"
@@ -833,13 +834,31 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
         for (const rt_gsphere &g : s->gspheres) s->gsph_derived.push_back(derive_gsphere(g));
         auto t0 = std::chrono::steady_clock::now();
         std::vector<Aabb> bounds(s->prims.size());
-        for (size_t i = 0; i < bounds.size(); i++) {
-            bounds[i] = prim_bounds(*s, s->prims[i]);
-            // NaN or infinite geometry would reach the builders' bucket and Morton casts
-            for (int k = 0; k < 3; k++)
-                if (!std::isfinite(bounds[i].lo[k]) || !std::isfinite(bounds[i].hi[k]) ||
-                    bounds[i].lo[k] > bounds[i].hi[k])
-                    return fail(RT_ERR_INVALID, "primitive %zu has no finite bounding box", i);
+        {
+            // every primitive's box; large scenes share the loop between the builders' threads
+            std::atomic<size_t> bad{SIZE_MAX}; // lowest primitive without a finite box
+            auto some = [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++) {
+                    bounds[i] = prim_bounds(*s, s->prims[i]);
+                    // NaN or infinite geometry would reach the builders' bucket and Morton casts
+                    bool ok = true;
+                    for (int k = 0; k < 3; k++)
+                        ok = ok && std::isfinite(bounds[i].lo[k]) && std::isfinite(bounds[i].hi[k]) &&
+                             bounds[i].lo[k] <= bounds[i].hi[k];
+                    if (!ok) {
+                        size_t seen = bad.load();
+                        while (i < seen && !bad.compare_exchange_weak(seen, i)) {}
+                    }
+                }
+            };
+            const size_t n = bounds.size();
+            const unsigned threads = n < (1u << 16) ? 1u : rt::build_threads();
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < threads; t++) pool.emplace_back(some, n * t / threads, n * (t + 1) / threads);
+            some(0, n / threads);
+            for (auto &t : pool) t.join();
+            if (bad.load() != SIZE_MAX)
+                return fail(RT_ERR_INVALID, "primitive %zu has no finite bounding box", bad.load());
         }
         s->enclosing = find_enclosing(*s, bounds);
         std::vector<uint32_t> in_tree; // primitives the tree is built over, when some are left out

@@ -19,6 +19,10 @@
 #include <cstring>
 
 #include <algorithm>
+#include <unordered_map>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "rt_bvh.hpp"
 
@@ -32,6 +36,7 @@ struct GNode {
     uint32_t treelet;
     uint32_t size;     // nodes in the subtree
     uint32_t index;    // pre-order index inside the treelet
+    uint32_t height;   // levels below this node (a leaf: 0)
     Aabb box;
 };
 
@@ -44,6 +49,55 @@ __device__ inline uint32_t spread3(uint32_t x) { // left_shift3, bvh.rs:903-912
     x = (x | (x << 4)) & 0x030c30c3u;
     x = (x | (x << 2)) & 0x09249249u;
     return x;
+}
+
+// Floats as unsigned integers of the same order, so that atomicMin / atomicMax on the integers
+// give the smallest / largest float (no NaNs here: primitive bounds are checked to be finite).
+__device__ inline uint32_t ordered(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float unordered(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &u, sizeof f);
+    return f;
+}
+
+// bounds of the centroids (bvh.rs:389-394): lo[3], hi[3] as ordered integers.  A thread walks
+// the primitives with the grid's stride, a wave reduces its lanes' results with shuffles and
+// adds six atomics (a few thousand waves: one wave per 64 primitives spent 12 ms on them).
+__global__ void k_centroid_bounds(const Aabb *bounds, uint32_t n, uint32_t *lohi) {
+    uint32_t lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) {
+        const Aabb b = bounds[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t c = ordered(b.lo[k] * 0.5f + b.hi[k] * 0.5f); // BVHPrimitiveInfo::new, bvh.rs:694-703
+            lo[k] = min(lo[k], c);
+            hi[k] = max(hi[k], c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        for (int s = 32; s > 0; s >>= 1) {
+            lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], s, 64));
+            hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], s, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&lohi[k], lo[k]);
+            atomicMax(&lohi[3 + k], hi[k]);
+        }
+    }
+}
+
+// treelets are maximal runs of sorted codes with equal top 12 bits (bvh.rs:414-431):
+// first[v] = where the run with top bits v starts (untouched when there is none)
+__global__ void k_treelet_starts(const uint32_t *codes, uint32_t n, uint32_t *first) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = codes[i] >> 18;
+    if (i == 0 || (codes[i - 1] >> 18) != v) first[v] = i;
 }
 
 // bvh.rs:396-406 with the scale applied before the cast (the text casts first)
@@ -192,6 +246,7 @@ __global__ void k_roots(const uint32_t *starts, uint32_t n_treelets, GNode *node
     g.treelet = t;
     g.size = 1;
     g.index = 0;
+    g.height = 0;
     g.box = Aabb{{0, 0, 0}, {0, 0, 0}};
     nodes[t] = g;
 }
@@ -227,6 +282,7 @@ __global__ void k_split(GNode *nodes, uint32_t begin, uint32_t end, const uint32
     a.treelet = g.treelet;
     a.size = 1;
     a.index = 0;
+    a.height = 0;
     a.box = Aabb{{0, 0, 0}, {0, 0, 0}};
     a.lo = g.lo;
     a.hi = g.lo + hi;
@@ -250,7 +306,7 @@ __global__ void k_up(GNode *nodes, uint32_t begin, uint32_t end, const Aabb *bou
     GNode g = nodes[id];
     const float m = 3.402823466e+38f;
     Aabb box{{m, m, m}, {-m, -m, -m}};
-    uint32_t size = 1;
+    uint32_t size = 1, height = 0;
     if (g.child[0] < 0) {
         if (g.hi - g.lo > 65535u) atomicAdd(too_many, 1u);
         for (uint32_t i = g.lo; i < g.hi; i++) {
@@ -267,9 +323,11 @@ __global__ void k_up(GNode *nodes, uint32_t begin, uint32_t end, const Aabb *bou
             box.hi[k] = pick_max(a.box.hi[k], b.box.hi[k]);
         }
         size = 1 + a.size + b.size;
+        height = 1 + max(a.height, b.height);
     }
     nodes[id].box = box;
     nodes[id].size = size;
+    nodes[id].height = height;
 }
 
 // pre-order indices inside the treelet, one level at a time from the roots
@@ -351,15 +409,16 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
         return RT_ERR_NO_DEVICE;
     }
     GPU_TRY(hipSetDevice(device));
-
-    // bounds of the centroids (bvh.rs:389-394): min / max, any order
-    Aabb cb = empty_box();
-    for (const Aabb &b : bounds)
-        for (int k = 0; k < 3; k++) {
-            const float c = b.lo[k] * 0.5f + b.hi[k] * 0.5f;
-            if (c < cb.lo[k]) cb.lo[k] = c;
-            if (c > cb.hi[k]) cb.hi[k] = c;
-        }
+    // RT355_BUILD_TIMES=1 prints where the build's time goes (stderr, milliseconds)
+    const bool times = getenv("RT355_BUILD_TIMES") != nullptr;
+    auto clock0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!times) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "rt355 build: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - clock0).count());
+        clock0 = now;
+    };
 
     DeviceMem mem;
     Aabb *d_bounds;
@@ -370,7 +429,23 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
     GPU_TRY(mem.get(&d_codes2, n));
     GPU_TRY(mem.get(&d_ids2, n));
     GPU_TRY(mem.get(&d_counter, 2));
+    mark("allocations");
     GPU_TRY(hipMemcpy(d_bounds, bounds.data(), n64 * sizeof(Aabb), hipMemcpyHostToDevice));
+    mark("bounds to device");
+    // bounds of the centroids (bvh.rs:389-394): min / max, exact in any order
+    Aabb cb;
+    {
+        uint32_t *d_lohi, lohi[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
+        GPU_TRY(mem.get(&d_lohi, 6));
+        GPU_TRY(hipMemcpy(d_lohi, lohi, sizeof lohi, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_centroid_bounds, dim3(std::min(blocks_for(n), 1024u)), dim3(kThreads), 0, nullptr, d_bounds, n, d_lohi);
+        GPU_TRY(hipMemcpy(lohi, d_lohi, sizeof lohi, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; k++) {
+            cb.lo[k] = unordered(lohi[k]);
+            cb.hi[k] = unordered(lohi[3 + k]);
+        }
+    }
+    mark("centroid bounds");
     hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_bounds, n, cb, d_codes, d_ids);
     GPU_TRY(hipGetLastError());
 
@@ -396,19 +471,25 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
         static_assert(kSortPasses % 2 == 1, "the sorted pairs are read from d_codes2 / d_ids2 below");
     }
 
+    mark("codes + sort");
     // treelets: maximal runs with equal top 12 bits (bvh.rs:414-431)
-    std::vector<uint32_t> codes(n);
     out.order.resize(n);
-    GPU_TRY(hipMemcpy(codes.data(), d_codes2, n64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     GPU_TRY(hipMemcpy(out.order.data(), d_ids2, n64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const uint32_t mask = 0x3ffc0000u;
     std::vector<uint32_t> starts;
-    for (uint32_t i = 0; i < n; i++)
-        if (i == 0 || (codes[i] & mask) != (codes[i - 1] & mask)) starts.push_back(i);
+    {
+        uint32_t *d_first;
+        std::vector<uint32_t> first(4096);
+        GPU_TRY(mem.get(&d_first, first.size()));
+        GPU_TRY(hipMemset(d_first, 0xff, first.size() * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_treelet_starts, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_codes2, n, d_first);
+        GPU_TRY(hipMemcpy(first.data(), d_first, first.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t f : first) // increasing top bits = increasing position in the sorted array
+            if (f != ~0u) starts.push_back(f);
+    }
     const uint32_t n_treelets = (uint32_t)starts.size();
     starts.push_back(n);
-    std::vector<uint32_t>().swap(codes);
 
+    mark("order to host; starts");
     uint32_t *d_starts, *d_base;
     GNode *d_nodes;
     const size_t capacity = 2 * n64 + n_treelets;
@@ -432,6 +513,7 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
         level.push_back(next);
     }
     const uint32_t n_nodes = level.back();
+    mark("allocate nodes; split levels");
     for (size_t k = level.size() - 1; k-- > 0;)
         hipLaunchKernelGGL(k_up, dim3(blocks_for(level[k + 1] - level[k])), dim3(kThreads), 0, nullptr, d_nodes, level[k],
                            level[k + 1], d_bounds, d_ids2, d_counter + 1);
@@ -446,6 +528,7 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
         return RT_ERR_LIMIT;
     }
 
+    mark("up, down");
     // the tree above the treelets, on the host
     std::vector<GNode> roots(n_treelets);
     GPU_TRY(hipMemcpy(roots.data(), d_nodes, (size_t)n_treelets * sizeof(GNode), hipMemcpyDeviceToHost));
@@ -458,16 +541,43 @@ int build_tree_hlbvh_device(const std::vector<Aabb> &bounds, uint32_t max_prims_
     std::vector<UpperNode> upper;
     const uint32_t total = hlbvh_upper(boxes, sizes, upper, base);
 
+    mark("upper tree (host)");
     rt_linear_node *d_out;
     GPU_TRY(mem.get(&d_out, total));
     GPU_TRY(hipMemcpy(d_base, base.data(), (size_t)n_treelets * sizeof(uint32_t), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(n_nodes)), dim3(kThreads), 0, nullptr, d_nodes, n_nodes, d_base, d_out);
     GPU_TRY(hipGetLastError());
+    mark("emit");
     out.nodes.resize(total);
+    mark("resize host nodes");
     GPU_TRY(hipMemcpy(out.nodes.data(), d_out, (size_t)total * sizeof(rt_linear_node), hipMemcpyDeviceToHost));
     for (const UpperNode &u : upper) out.nodes[u.index] = u.node;
+    mark("nodes to host");
 
-    out.max_depth = tree_depth(out.nodes);
+    // Stack entries the traversal can need (tree_depth): the deepest leaf.  Inside a treelet that
+    // is its root's height (from k_up); the treelet roots' own depths come from a walk over the
+    // few nodes above them.
+    {
+        std::unordered_map<uint32_t, uint32_t> treelet_at, upper_at; // node index -> treelet / upper node
+        for (uint32_t t = 0; t < n_treelets; t++) treelet_at[base[t]] = t;
+        for (size_t k = 0; k < upper.size(); k++) upper_at[upper[k].index] = (uint32_t)k;
+        uint32_t deepest = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
+        while (!todo.empty()) {
+            const auto [idx, depth] = todo.back();
+            todo.pop_back();
+            const auto t = treelet_at.find(idx);
+            if (t != treelet_at.end()) {
+                deepest = std::max(deepest, depth + roots[t->second].height);
+            } else {
+                const rt_linear_node &u = upper[upper_at.at(idx)].node;
+                todo.push_back({idx + 1, depth + 1});
+                todo.push_back({u.child_offset, depth + 1});
+            }
+        }
+        out.max_depth = deepest + 1;
+    }
+    mark("tree depth");
     if (out.max_depth > 64) { // nodes_to_visit = [0; 64], bvh.rs:753
         err = "tree needs " + std::to_string(out.max_depth) + " stack entries, the traversal stack holds 64";
         return RT_ERR_DEPTH;

@@ -198,10 +198,7 @@ class Builder {
     };
 
     int32_t parallel_top_down(uint32_t n) {
-        unsigned threads = std::thread::hardware_concurrency();
-        if (const char *e = getenv("RT355_BUILD_THREADS")) threads = (unsigned)atoi(e);
-        else if (const char *e2 = getenv("OMP_NUM_THREADS")) threads = std::min(threads, (unsigned)atoi(e2));
-        threads = std::max(1u, std::min(threads, 64u));
+        const unsigned threads = build_threads();
         if (threads == 1 || n < (1u << 16)) return top_down(pool_, 0, n, nullptr);
         grain_ = std::max(4096u, n / (threads * 8));
         std::vector<Task> tasks;
@@ -491,6 +488,13 @@ uint32_t hlbvh_upper(const std::vector<Aabb> &boxes, const std::vector<uint32_t>
     } walk{b.pool_, sizes, upper, base, next};
     walk.go(root);
     return next;
+}
+
+unsigned build_threads() {
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char *e = getenv("RT355_BUILD_THREADS")) threads = (unsigned)atoi(e);
+    else if (const char *e2 = getenv("OMP_NUM_THREADS")) threads = std::min(threads, (unsigned)atoi(e2));
+    return std::max(1u, std::min(threads, 64u));
 }
 
 uint32_t tree_depth(const std::vector<rt_linear_node> &nodes) {

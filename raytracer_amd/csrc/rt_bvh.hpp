@@ -34,6 +34,10 @@ int build_tree(const std::vector<Aabb> &bounds, uint32_t max_prims_in_node, uint
 
 uint32_t tree_depth(const std::vector<rt_linear_node> &nodes);
 
+// Host threads the builders use: the machine's, capped by OMP_NUM_THREADS and 64, or
+// RT355_BUILD_THREADS when set.
+unsigned build_threads();
+
 // The part of an HLBVH above its treelets (build_upper_sah, bvh.rs:541-658) for treelets
 // built elsewhere.  In: box and node count of every treelet, in Morton order.  Out: the
 // interior nodes above the treelets with their indices in the final pre-order array, and
