@@ -78,7 +78,7 @@ pub struct rt_build_opts { pub max_prims_in_node: u32, pub split_method: u32, pu
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_linear_node { pub lo: [f32; 3], pub hi: [f32; 3], pub child_offset: u32, pub primitive_count: u16, pub axis: u8, pub _pad: u8 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
-pub struct rt_scene_info { pub n_prims: u32, pub n_nodes: u32, pub max_depth: u32, pub stack_slots: u32, pub device_bytes: u64, pub build_ms: f64, pub n_enclosing: u32, pub enclosing: [u32; 4], pub _pad: u32 }
+pub struct rt_scene_info { pub n_prims: u32, pub n_nodes: u32, pub max_depth: u32, pub stack_slots: u32, pub device_bytes: u64, pub build_ms: f64, pub n_enclosing: u32, pub enclosing: [u32; 4], pub n_balls: u32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_camera { pub raster_to_camera: [f32; 16], pub camera_to_world: [f32; 12], pub lens_radius: f32, pub focal_distance: f32, pub shutter_open: f32, pub shutter_close: f32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]

@@ -235,7 +235,7 @@ typedef struct rt_scene_info {
     double build_ms;
     uint32_t n_enclosing; /* media enclosing the scene, kept out of the tree (see rt_scene_create) */
     uint32_t enclosing[4]; /* their primitive indices, ascending                                  */
-    uint32_t _pad;
+    uint32_t n_balls;      /* sphere-bounded media nothing else reaches into (see rt_scene_create) */
 } rt_scene_info;
 
 /* Perspective camera: colour/src/camera/perspective.rs:16-78 with

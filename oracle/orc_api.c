@@ -164,6 +164,7 @@ int orc_scene_get_info(const orc_scene *s, rt_scene_info *out) {
     out->build_ms = s->build_ms;
     out->n_enclosing = s->n_enclosing;
     for (uint32_t k = 0; k < s->n_enclosing; k++) out->enclosing[k] = s->enclosing[k];
+    out->n_balls = s->n_balls;
     return RT_OK;
 }
 

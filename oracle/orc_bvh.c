@@ -455,18 +455,119 @@ static void find_enclosing(orc_scene *s, const aabb *bounds) {
     }
 }
 
+/* Balls.  The scene files hold a glass sphere filled with fog (test/week.toml: a Volume bounded
+ * by the sphere that is also a dielectric primitive); a path that gets inside stays there for
+ * dozens of segments, each of which would walk the tree from the root only to find the two
+ * primitives it started in.  A ball is a medium bounded by a sphere (no instance transform, not
+ * one of the enclosing media), optionally with one sphere primitive of bit-identical centre and
+ * positive radius, such that no other primitive of the tree comes nearer to the sphere than a
+ * safety distance: for a sphere-like primitive the distance between the surfaces, for any other
+ * the distance from the ball's centre to the primitive's box minus the radius, must exceed
+ * 0.002 x (radius + half the diagonal of the other's box).  A ray that starts inside such a ball
+ * (|o - c|^2 < (0.998 r)^2) meets everything else only after it has left the ball, so its
+ * closest hit is decided by the ball's own primitives: see ball_resolve.  The first
+ * ORC_MAX_BALLS balls in primitive order are kept.  Same rule, same arithmetic in the library. */
+static void find_balls(orc_scene *s, const aabb *bounds) {
+    s->n_balls = 0;
+    if (getenv("ORC_NO_BALLS")) return; /* tests compare results with and without the short cut */
+    for (uint32_t i = 0; i < s->n_prims && s->n_balls < ORC_MAX_BALLS; i++) {
+        const rt_prim_ref *p = &s->prims[i];
+        if ((p->kind & 0xffu) != RT_MEDIUM) continue;
+        const rt_medium *m = &s->media[p->index];
+        if (m->boundary_kind != RT_BOUNDARY_SPHERE || m->xform != 0) continue;
+        int skip = 0;
+        for (uint32_t e = 0; e < s->n_enclosing; e++) skip |= s->enclosing[e] == i;
+        if (skip) continue;
+        const rt_sphere *sp = &s->spheres[m->boundary_index];
+        if (!(sp->r > 0.0f)) continue;
+        orc_ball b;
+        memcpy(b.c, sp->c, sizeof b.c);
+        b.r = sp->r;
+        const double rin = (double)sp->r * 0.998;
+        b.r_in2 = (float)(rin * rin);
+        b.n = 1;
+        b.prim[0] = i;
+        b.sphere = -1;
+        int ok = 1;
+        for (uint32_t j = 0; j < s->n_prims && ok; j++) {
+            if (j == i) continue;
+            int enclosing = 0;
+            for (uint32_t e = 0; e < s->n_enclosing; e++) enclosing |= s->enclosing[e] == j;
+            if (enclosing) continue; /* not in the tree; every ray tests them first anyway */
+            const rt_prim_ref *q = &s->prims[j];
+            const uint32_t kind = q->kind & 0xffu;
+            const rt_sphere *other = NULL;
+            if (kind == RT_SPHERE) other = &s->spheres[q->index];
+            else if (kind == RT_MEDIUM && s->media[q->index].boundary_kind == RT_BOUNDARY_SPHERE &&
+                     s->media[q->index].xform == 0)
+                other = &s->spheres[s->media[q->index].boundary_index];
+            if (kind == RT_SPHERE && other->r > 0.0f && memcmp(other->c, sp->c, sizeof sp->c) == 0 &&
+                memcmp(&other->r, &sp->r, sizeof sp->r) == 0 && b.sphere < 0) {
+                b.sphere = (int)j; /* the shell: position fixed below */
+                continue;
+            }
+            const double hx = ((double)bounds[j].hi.x - (double)bounds[j].lo.x) * 0.5;
+            const double hy = ((double)bounds[j].hi.y - (double)bounds[j].lo.y) * 0.5;
+            const double hz = ((double)bounds[j].hi.z - (double)bounds[j].lo.z) * 0.5;
+            const double safety = 0.002 * ((double)sp->r + sqrt(hx * hx + hy * hy + hz * hz));
+            double gap;
+            if (other) {
+                const double dx = (double)other->c[0] - (double)sp->c[0], dy = (double)other->c[1] - (double)sp->c[1],
+                             dz = (double)other->c[2] - (double)sp->c[2];
+                gap = sqrt(dx * dx + dy * dy + dz * dz) - fabs((double)other->r) - (double)sp->r;
+            } else {
+                const double cx = sp->c[0], cy = sp->c[1], cz = sp->c[2];
+                const double px = cx < bounds[j].lo.x ? bounds[j].lo.x : (cx > bounds[j].hi.x ? bounds[j].hi.x : cx);
+                const double py = cy < bounds[j].lo.y ? bounds[j].lo.y : (cy > bounds[j].hi.y ? bounds[j].hi.y : cy);
+                const double pz = cz < bounds[j].lo.z ? bounds[j].lo.z : (cz > bounds[j].hi.z ? bounds[j].hi.z : cz);
+                gap = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy) + (pz - cz) * (pz - cz)) - (double)sp->r;
+            }
+            if (!(gap > safety)) ok = 0;
+        }
+        if (!ok) continue;
+        if (b.sphere >= 0) {
+            b.n = 2;
+            b.prim[1] = (uint32_t)b.sphere; /* order by leaf position: set after the build */
+            b.sphere = 1;
+        }
+        s->balls[s->n_balls++] = b;
+    }
+}
+
+/* the ball's primitives in the order the leaves hold them (the order the traversal would test
+ * them in when they share a leaf) */
+static void order_balls(orc_scene *s) {
+    for (uint32_t k = 0; k < s->n_balls; k++) {
+        orc_ball *b = &s->balls[k];
+        if (b->n != 2) continue;
+        uint32_t at[2] = {0, 0};
+        for (uint32_t i = 0; i < s->n_tree_prims; i++) {
+            if (s->order[i] == b->prim[0]) at[0] = i;
+            if (s->order[i] == b->prim[1]) at[1] = i;
+        }
+        if (at[1] < at[0]) {
+            const uint32_t t = b->prim[0];
+            b->prim[0] = b->prim[1];
+            b->prim[1] = t;
+            b->sphere = 0;
+        }
+    }
+}
+
 int orc_build(orc_scene *s, const rt_build_opts *opts) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     s->n_nodes = 0;
     s->max_depth = 0;
     s->n_enclosing = 0;
+    s->n_balls = 0;
     s->n_tree_prims = s->n_prims;
     if (s->n_prims == 0) return RT_OK;
     aabb *bounds = (aabb *)malloc((size_t)s->n_prims * sizeof *bounds);
     if (!bounds) { orc_set_error("out of memory building tree"); return RT_ERR_NOMEM; }
     for (uint32_t i = 0; i < s->n_prims; i++) bounds[i] = orc_prim_bounds(s, i);
     find_enclosing(s, bounds);
+    find_balls(s, bounds);
     s->n_tree_prims = s->n_prims - s->n_enclosing;
     uint32_t n = s->n_tree_prims;
     builder B;
@@ -505,6 +606,7 @@ int orc_build(orc_scene *s, const rt_build_opts *opts) {
             if (!p->child[0] && p->count > 65535) rc = RT_ERR_LIMIT;
         if (rc == RT_OK) {
             flatten(s, root);
+            order_balls(s);
             s->max_depth = orc_tree_depth(s->nodes, s->n_nodes);
             if (s->max_depth > 64) { /* nodes_to_visit = [0; 64], bvh.rs:753 */
                 orc_set_error("tree needs %u stack entries, the traversal stack holds 64",
@@ -544,6 +646,62 @@ int orc_slab(const rt_linear_node *n, const rt_ray *ray, const float inv[3], con
     return t_min < ray->t_max && t_max > 0.0f;
 }
 
+/* A ray that starts inside a ball (find_balls), after the enclosing media have been tested:
+ * everything outside the ball lies beyond the point where the ray leaves it, so if the ball's
+ * own primitives decide the hit the tree need not be walked.  They do when
+ *   - with a shell: the shell is hit at all (t_max = infinity), so the ray does leave through it,
+ *     and testing the ball's primitives in either order gives the same winner and distance
+ *     (the traversal may meet them in either order; only an exact tie tells the orders apart);
+ *   - without a shell: the medium scatters the ray (nothing else can come before that).
+ * Then *ray, *found, *best_prim, best_aux are the traversal's result and 1 is returned; the
+ * counters take one test per primitive of the ball and no node.  Otherwise nothing is changed,
+ * 0 is returned and the traversal runs as usual. */
+static int ball_resolve(const orc_scene *s, rt_ray *ray, int *found, uint32_t *best_prim, float best_aux[4],
+                        uint64_t counters[9]) {
+    for (uint32_t k = 0; k < s->n_balls; k++) {
+        const orc_ball *b = &s->balls[k];
+        const float dx = ray->o[0] - b->c[0], dy = ray->o[1] - b->c[1], dz = ray->o[2] - b->c[2];
+        if (!(dx * dx + dy * dy + dz * dz < b->r_in2)) continue;
+        if (b->sphere >= 0) {
+            rt_ray far = *ray;
+            far.t_max = INFINITY;
+            float t, aux[4] = {0, 0, 0, 0};
+            if (!orc_prim_test(s, b->prim[b->sphere], &far, &t, aux)) return 0;
+        }
+        rt_ray r[2];
+        int f[2] = {0, 0};
+        uint32_t bp[2] = {0, 0};
+        float ba[2][4];
+        for (uint32_t order = 0; order < b->n; order++) {
+            r[order] = *ray;
+            f[order] = *found;
+            bp[order] = *best_prim;
+            memcpy(ba[order], best_aux, sizeof ba[order]);
+            for (uint32_t q = 0; q < b->n; q++) {
+                const uint32_t prim = b->prim[order == 0 ? q : b->n - 1 - q];
+                float t, aux[4] = {0, 0, 0, 0};
+                if (orc_prim_test(s, prim, &r[order], &t, aux)) {
+                    r[order].t_max = t;
+                    f[order] = 1;
+                    bp[order] = prim;
+                    memcpy(ba[order], aux, sizeof aux);
+                }
+            }
+        }
+        if (b->n == 2 && (f[0] != f[1] || bp[0] != bp[1] || memcmp(&r[0].t_max, &r[1].t_max, sizeof(float)) != 0))
+            return 0;
+        if (b->sphere < 0 && !(f[0] && bp[0] == b->prim[0])) return 0;
+        if (counters)
+            for (uint32_t q = 0; q < b->n; q++) counters[1 + (s->prims[b->prim[q]].kind & 0xffu)]++;
+        *ray = r[0];
+        *found = f[0];
+        *best_prim = bp[0];
+        memcpy(best_aux, ba[0], sizeof ba[0]);
+        return 1;
+    }
+    return 0;
+}
+
 /* closest hit, bvh.rs:736-799.  The reference keeps the last primitive hit and
  * never shortens the ray (its Primitive::intersect returns no distance); here
  * t_max shrinks on every accepted hit, ties go to the later primitive. */
@@ -565,6 +723,10 @@ int orc_closest(const orc_scene *s, const rt_ray *ray_in, orc_surf *out, uint64_
             best_prim = s->enclosing[e];
             memcpy(best_aux, aux, sizeof aux);
         }
+    }
+    if (ball_resolve(s, &ray, &found, &best_prim, best_aux, counters)) {
+        if (found && out) orc_prim_finalize(s, best_prim, ray_in, ray.t_max, best_aux, out);
+        return found;
     }
     for (; s->n_nodes != 0;) {
         const rt_linear_node *node = &s->nodes[cur];

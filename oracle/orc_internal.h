@@ -8,6 +8,17 @@
 typedef struct { v3 lo, hi; } aabb;
 
 #define ORC_MAX_ENCLOSING 4
+#define ORC_MAX_BALLS 4
+
+/* A medium bounded by a sphere that nothing else reaches into, with or without a sphere
+ * primitive of exactly that geometry around it (see find_balls in orc_bvh.c). */
+typedef struct {
+    float c[3], r;
+    float r_in2;      /* a ray starts "inside" when |o - c|^2 < r_in2 */
+    uint32_t n;       /* primitives of the ball: 1 (the medium) or 2 */
+    uint32_t prim[2]; /* in the order the tree's leaves hold them */
+    int sphere;       /* which of them is the sphere primitive, or -1 */
+} orc_ball;
 
 /* Bounds3::ZERO is the inverted box [+MAX, -MAX], geometry/src/bounds3.rs:23-26 */
 static inline aabb aabb_empty(void) {
@@ -67,6 +78,8 @@ struct orc_scene {
      * them, so they are tested once per ray, before the traversal, in this order. */
     uint32_t n_enclosing, enclosing[ORC_MAX_ENCLOSING];
     uint32_t n_tree_prims; /* n_prims - n_enclosing */
+    uint32_t n_balls;
+    orc_ball balls[ORC_MAX_BALLS];
     /* tree over the other primitives */
     rt_linear_node *nodes;
     uint32_t n_nodes;

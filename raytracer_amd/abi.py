@@ -84,7 +84,7 @@ RT_BUILD_ON_DEVICE = 1
 class rt_scene_info(C.Structure):
     _fields_ = [("n_prims", C.c_uint32), ("n_nodes", C.c_uint32), ("max_depth", C.c_uint32),
                 ("stack_slots", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_double),
-                ("n_enclosing", C.c_uint32), ("enclosing", C.c_uint32 * 4), ("_pad", C.c_uint32)]
+                ("n_enclosing", C.c_uint32), ("enclosing", C.c_uint32 * 4), ("n_balls", C.c_uint32)]
 
 
 class rt_camera(C.Structure):

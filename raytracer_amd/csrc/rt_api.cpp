@@ -144,6 +144,13 @@ struct rt_scene {
     // media that enclose the scene: kept out of the tree, tested once per ray before the
     // traversal (find_enclosing); caller's primitive indices in ascending order
     std::vector<uint32_t> enclosing;
+    // balls (find_balls): a ray that starts inside one may be resolved by the ball's primitives alone
+    struct Ball {
+        uint32_t medium;    // the medium's primitive index
+        int64_t sphere;     // the shell's primitive index, or -1
+        float c[3], r, r_in2;
+    };
+    std::vector<Ball> balls;
     rt::BuiltTree tree;
     double build_ms = 0;
     mutable std::mutex lock;
@@ -302,6 +309,78 @@ std::vector<uint32_t> find_enclosing(const rt_scene &s, const std::vector<Aabb> 
             inside = dx * dx + dy * dy + dz * dz < (double)sp.r * (double)sp.r;
         }
         if (inside) out.push_back((uint32_t)i);
+    }
+    return out;
+}
+
+// Balls.  The scene files hold a glass sphere filled with fog (test/week.toml: a Volume bounded
+// by the sphere that is also a dielectric primitive); a path that gets inside stays there for
+// dozens of segments, each of which would walk the tree from the root only to find the two
+// primitives it started in.  A ball is a medium bounded by a sphere (no instance transform, not
+// one of the enclosing media), optionally with one sphere primitive of bit-identical centre and
+// positive radius, such that no other primitive of the tree comes nearer to the sphere than a
+// safety distance: for a sphere-like primitive the distance between the surfaces, for any other
+// the distance from the ball's centre to the primitive's box minus the radius, must exceed
+// 0.002 x (radius + half the diagonal of the other's box).  A ray that starts inside such a ball
+// (|o - c|^2 < (0.998 r)^2) meets everything else only after it has left the ball, so its
+// closest hit is decided by the ball's own primitives (ball_resolve in rt_kernels.hip).  The
+// first kMaxBalls balls in primitive order are kept.  RT355_NO_BALLS=1 finds none (a test hook:
+// results must not depend on it).
+std::vector<rt_scene::Ball> find_balls(const rt_scene &s, const std::vector<Aabb> &bounds) {
+    std::vector<rt_scene::Ball> out;
+    if (getenv("RT355_NO_BALLS")) return out;
+    auto is_enclosing = [&](size_t i) {
+        for (uint32_t e : s.enclosing)
+            if (e == i) return true;
+        return false;
+    };
+    for (size_t i = 0; i < s.prims.size() && out.size() < rt::kMaxBalls; i++) {
+        const rt_prim_ref &p = s.prims[i];
+        if ((p.kind & 0xffu) != RT_MEDIUM) continue;
+        const rt_medium &m = s.media[p.index];
+        if (m.boundary_kind != RT_BOUNDARY_SPHERE || m.xform != 0 || is_enclosing(i)) continue;
+        const rt_sphere &sp = s.spheres[m.boundary_index];
+        if (!(sp.r > 0.0f)) continue;
+        rt_scene::Ball b;
+        b.medium = (uint32_t)i;
+        b.sphere = -1;
+        memcpy(b.c, sp.c, sizeof b.c);
+        b.r = sp.r;
+        const double rin = (double)sp.r * 0.998;
+        b.r_in2 = (float)(rin * rin);
+        bool ok = true;
+        for (size_t j = 0; j < s.prims.size() && ok; j++) {
+            if (j == i || is_enclosing(j)) continue; // those are not in the tree; every ray tests them first anyway
+            const rt_prim_ref &q = s.prims[j];
+            const uint32_t kind = q.kind & 0xffu;
+            const rt_sphere *other = nullptr;
+            if (kind == RT_SPHERE) other = &s.spheres[q.index];
+            else if (kind == RT_MEDIUM && s.media[q.index].boundary_kind == RT_BOUNDARY_SPHERE && s.media[q.index].xform == 0)
+                other = &s.spheres[s.media[q.index].boundary_index];
+            if (kind == RT_SPHERE && other->r > 0.0f && memcmp(other->c, sp.c, sizeof sp.c) == 0 &&
+                memcmp(&other->r, &sp.r, sizeof sp.r) == 0 && b.sphere < 0) {
+                b.sphere = (int64_t)j; // the shell
+                continue;
+            }
+            const double hx = ((double)bounds[j].hi[0] - (double)bounds[j].lo[0]) * 0.5;
+            const double hy = ((double)bounds[j].hi[1] - (double)bounds[j].lo[1]) * 0.5;
+            const double hz = ((double)bounds[j].hi[2] - (double)bounds[j].lo[2]) * 0.5;
+            const double safety = 0.002 * ((double)sp.r + sqrt(hx * hx + hy * hy + hz * hz));
+            double gap;
+            if (other) {
+                const double dx = (double)other->c[0] - (double)sp.c[0], dy = (double)other->c[1] - (double)sp.c[1],
+                             dz = (double)other->c[2] - (double)sp.c[2];
+                gap = sqrt(dx * dx + dy * dy + dz * dz) - fabs((double)other->r) - (double)sp.r;
+            } else {
+                const double cx = sp.c[0], cy = sp.c[1], cz = sp.c[2];
+                const double px = cx < bounds[j].lo[0] ? bounds[j].lo[0] : (cx > bounds[j].hi[0] ? bounds[j].hi[0] : cx);
+                const double py = cy < bounds[j].lo[1] ? bounds[j].lo[1] : (cy > bounds[j].hi[1] ? bounds[j].hi[1] : cy);
+                const double pz = cz < bounds[j].lo[2] ? bounds[j].lo[2] : (cz > bounds[j].hi[2] ? bounds[j].hi[2] : cz);
+                gap = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy) + (pz - cz) * (pz - cz)) - (double)sp.r;
+            }
+            if (!(gap > safety)) ok = false;
+        }
+        if (ok) out.push_back(b);
     }
     return out;
 }
@@ -632,6 +711,35 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     D.n_prims = (uint32_t)leaf.size();
     D.n_tree_prims = (uint32_t)n_tree_prims;
     D.n_enclosing = (uint32_t)s.enclosing.size();
+    // balls: the leaf slots of their primitives, in leaf order
+    D.n_balls = 0;
+    for (const rt_scene::Ball &b : s.balls) {
+        int64_t at_medium = -1, at_sphere = -1;
+        for (size_t k = 0; k < leaf.size(); k++) {
+            if (leaf[k].prim == b.medium) at_medium = (int64_t)k;
+            if (b.sphere >= 0 && leaf[k].prim == (uint32_t)b.sphere) at_sphere = (int64_t)k;
+        }
+        if (at_medium < 0 || (b.sphere >= 0 && at_sphere < 0)) continue;
+        rt::BallDev &o = D.balls[D.n_balls++];
+        memcpy(o.c, b.c, sizeof o.c);
+        o.r = b.r;
+        o.r_in2 = b.r_in2;
+        auto best_of = [&](int64_t k) {
+            return (uint32_t)k | ((leaf[(size_t)k].kind & rt::kRareShade) ? 0x80000000u : 0u);
+        };
+        if (b.sphere < 0) {
+            o.n = 1;
+            o.best[0] = o.best[1] = best_of(at_medium);
+            o.sphere = -1;
+            o.medium = 0;
+        } else {
+            o.n = 2;
+            o.sphere = at_sphere < at_medium ? 0 : 1;
+            o.medium = 1u - (uint32_t)o.sphere;
+            o.best[o.sphere] = best_of(at_sphere);
+            o.best[o.medium] = best_of(at_medium);
+        }
+    }
     D.enclosing_rare = 0;
     for (size_t e = 0; e < s.enclosing.size(); e++)
         if (leaf[n_tree_prims + e].kind & rt::kRareShade) D.enclosing_rare |= 1u << e;
@@ -751,7 +859,7 @@ int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
         if ((rc = take(entries * sizeof(float4), (void **)&db.q[k].c))) return rc;
         if ((rc = take(entries * sizeof(uint2), (void **)&db.q[k].d))) return rc;
         db.q[k].e = nullptr;
-        if (db.dev.n_enclosing && (rc = take(entries * sizeof(uint2), (void **)&db.q[k].e))) return rc;
+        if ((db.dev.n_enclosing || db.dev.n_balls) && (rc = take(entries * sizeof(uint2), (void **)&db.q[k].e))) return rc;
         db.q[k].cap = cap;
     }
     if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.radiance))) return rc;
@@ -861,6 +969,7 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
                 return fail(RT_ERR_INVALID, "primitive %zu has no finite bounding box", bad.load());
         }
         s->enclosing = find_enclosing(*s, bounds);
+        s->balls = find_balls(*s, bounds);
         std::vector<uint32_t> in_tree; // primitives the tree is built over, when some are left out
         if (!s->enclosing.empty()) {
             size_t e = 0;
@@ -932,6 +1041,7 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     }
     out->build_ms = s->build_ms;
     out->n_enclosing = (uint32_t)s->enclosing.size();
+    out->n_balls = (uint32_t)s->balls.size();
     for (size_t k = 0; k < s->enclosing.size() && k < 4; k++) out->enclosing[k] = s->enclosing[k];
     return RT_OK;
 }
@@ -1369,7 +1479,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         max_paths = 1u << 27;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t per_path = 2 * (3 * sizeof(float4) + sizeof(uint2) + (db->dev.n_enclosing ? sizeof(uint2) : 0)) +
+            const size_t per_path = 2 * (3 * sizeof(float4) + sizeof(uint2) + (db->dev.n_enclosing || db->dev.n_balls ? sizeof(uint2) : 0)) +
                                     sizeof(float4) + ((o->flags & RT_RENDER_DIRECT_LIGHT) ? 3 * sizeof(float4) : 0);
             const size_t held = (size_t)db->ws_paths * per_path;
             const size_t fit = (free_b + held) / 2 / per_path;

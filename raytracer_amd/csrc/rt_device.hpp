@@ -73,6 +73,20 @@ struct PlainShade { // 48 B
     float b[3], _pad;
 };
 
+// A ball: a medium bounded by a sphere that no other primitive of the tree reaches into, with or
+// without a sphere primitive of exactly that geometry around it (a glass ball filled with fog).
+// A ray that starts inside meets everything else only after it has left the ball, so the ball's
+// own primitives can decide its closest hit without a walk through the tree (ball_resolve).
+constexpr uint32_t kMaxBalls = 4;
+struct BallDev { // 40 B
+    float c[3], r;
+    float r_in2;      // a ray starts inside when |o - c|^2 < r_in2
+    uint32_t n;       // primitives of the ball: 1 (the medium) or 2
+    uint32_t best[2]; // their leaf slots in leaf order, with kBestRare where a hit needs the general shader
+    int32_t sphere;   // which of them is the sphere primitive, or -1
+    uint32_t medium;  // which is the medium
+};
+
 struct ImageDev {
     const uint8_t *rgb8;
     uint32_t w, h;
@@ -108,6 +122,8 @@ struct SceneDev {
     // n_tree_prims primitives in `leaf`, and every ray tests them before it starts traversing.
     uint32_t n_tree_prims, n_enclosing;
     uint32_t enclosing_rare; // bit e: a scatter in enclosing medium e needs the general shader
+    uint32_t n_balls;
+    BallDev balls[kMaxBalls];
     uint32_t n_pairs;          // interior records in `nodes`
     uint32_t root_ref;         // reference to the root (a leaf when the tree is a single node)
     uint32_t stack_lds;        // stack levels per lane kept in LDS; deeper entries use private memory
@@ -510,6 +526,23 @@ RT_DEV float medium_uniform(const Ray &ray, uint32_t prim) {
     h = hash32(h ^ __float_as_uint(ray.o.x));
     return (float)(h >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
 }
+// The medium's test after the boundary's: the ray crosses the boundary between t_in and t_out_b
+// (medium_span clips that to the ray), its direction has length len, and the medium wants to
+// scatter it hit_dist further on (medium_scatter).
+RT_DEV bool medium_span(float &t_in, float &t_out_b, float t_max) {
+    if (t_in < 0.0f) t_in = 0.0f;
+    if (t_out_b > t_max) t_out_b = t_max;
+    return t_in < t_out_b;
+}
+RT_DEV bool medium_scatter(float t_in, float t_out_b, float t_max, float len, float hit_dist, float &t_out) {
+    float inside = (t_out_b - t_in) * len;
+    if (hit_dist > inside) return false;
+    float t = t_in + hit_dist / len;
+    if (!(t > 0.0f && t <= t_max)) return false;
+    t_out = t;
+    return true;
+}
+
 RT_DEV bool medium_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, v3 rd, float &t_out) {
     float t_in, t_out_b, neg_inv_density;
     if (lp.kind & kMediumInSphere) { // everything the test needs is in the leaf entry
@@ -529,17 +562,10 @@ RT_DEV bool medium_test(const SceneDev &S, const LeafPrim &lp, const Ray &ray, v
             if (!box_interval(o, d, load_box(S.boxes, m.boundary_index), t_in, t_out_b, fn, ff)) return false;
         }
     }
-    if (t_in < 0.0f) t_in = 0.0f;
-    if (t_out_b > ray.t_max) t_out_b = ray.t_max;
-    if (!(t_in < t_out_b)) return false;
-    float len = length(ray.d);
-    float inside = (t_out_b - t_in) * len;
-    float hit_dist = neg_inv_density * p_log(medium_uniform(ray, lp.prim));
-    if (hit_dist > inside) return false;
-    float t = t_in + hit_dist / len;
-    if (!(t > 0.0f && t <= ray.t_max)) return false;
-    t_out = t;
-    return true;
+    if (!medium_span(t_in, t_out_b, ray.t_max)) return false;
+    const float len = length(ray.d);
+    const float hit_dist = neg_inv_density * p_log(medium_uniform(ray, lp.prim));
+    return medium_scatter(t_in, t_out_b, ray.t_max, len, hit_dist, t_out);
 }
 
 // ---- one primitive ---------------------------------------------------------------------

@@ -279,6 +279,108 @@ struct Blocks {
     }
 };
 
+// A ray that starts inside a ball (BallDev), after the media that enclose the scene have been
+// tested (ray.t_max, best0 = what they left): if the ball's own primitives decide the closest
+// hit, t_out / won say how and true is returned; the tree need not be walked for this ray.
+// They do when
+//   - with a shell: the shell is hit at all (t_max = infinity), so the ray does leave through
+//     it, and testing the ball's primitives in either order gives the same winner and distance
+//     (the traversal may meet them in either order; only an exact tie tells the orders apart);
+//   - without a shell: the medium scatters the ray (nothing else can come before that).
+// won: 0 / 1 = the ball's primitive in leaf order, 2 = nothing of the ball (the ray ends
+// inside it or in an enclosing medium: what came in stands).
+RT_DEV bool ball_resolve(const SceneDev &S, const BallDev &b, const Ray &ray, float &t_out, uint32_t &won) {
+    float t0, t1;
+    if (!sphere_roots(ray.o - mk(b.c[0], b.c[1], b.c[2]), ray.d, b.r, t0, t1)) return false;
+    float t_shell = 0.0f;
+    if (b.sphere >= 0 && !sphere_pick(t0, t1, kInf, t_shell)) return false;
+    // the medium's wish does not depend on the ray's end
+    const LeafPrim lm = S.leaf[b.best[b.medium] & ~kBestRare];
+    const float len = length(ray.d);
+    const float hit_dist = __uint_as_float(lm.index) * p_log(medium_uniform(ray, lm.prim));
+    float t_end[2];
+    uint32_t win[2];
+#pragma unroll
+    for (uint32_t order = 0; order < 2; order++) {
+        float t_max = ray.t_max;
+        uint32_t w = 2;
+        for (uint32_t q = 0; q < b.n; q++) {
+            const uint32_t j = order == 0 ? q : b.n - 1 - q;
+            float t;
+            bool hit;
+            if ((int32_t)j == b.sphere) {
+                hit = sphere_pick(t0, t1, t_max, t);
+            } else {
+                float t_in = t0, t_out_b = t1;
+                hit = medium_span(t_in, t_out_b, t_max) && medium_scatter(t_in, t_out_b, t_max, len, hit_dist, t);
+            }
+            if (hit) {
+                t_max = t;
+                w = j;
+            }
+        }
+        t_end[order] = t_max;
+        win[order] = w;
+    }
+    if (b.n == 2 && (win[0] != win[1] || __float_as_uint(t_end[0]) != __float_as_uint(t_end[1]))) return false;
+    if (b.sphere < 0 && win[0] != 0) return false;
+    t_out = t_end[0];
+    won = win[0];
+    return true;
+}
+
+// What the maker of a ray finds out about it before it is queued, where all lanes of a full wave
+// work (camera rays, scattered rays) instead of in the traversal that picks the ray up later
+// with a few lanes: the media that enclose the scene (the same tests in the same order on the
+// same ray as trace_stream makes for rays that come without this) and, for a ray that starts
+// inside a ball, its closest hit.  t_max: the ray's end after all that.  code: bits 0-7 = 0, or
+// k when the ray scatters in the k-th enclosing medium; bits 8-15 = 0, or 1 + 3 ball + won when
+// the ray is resolved (ball_resolve) and needs no traversal.
+RT_DEV void pretest(const SceneDev &S, const Ray &ray, float &t_max, uint32_t &code) {
+    Ray r = ray;
+    uint32_t which = 0;
+    const v3 rd = mk(0.0f, 0.0f, 0.0f); // only boxes read the reciprocal direction; these are spheres
+    for (uint32_t e = 0; e < S.n_enclosing; e++) {
+        const LeafPrim lp = S.leaf[S.n_tree_prims + e];
+        float t;
+        if (medium_test(S, lp, r, rd, t)) {
+            r.t_max = t;
+            which = e + 1;
+        }
+    }
+    code = which;
+    for (uint32_t k = 0; k < S.n_balls; k++) {
+        const BallDev &b = S.balls[k];
+        const float dx = r.o.x - b.c[0], dy = r.o.y - b.c[1], dz = r.o.z - b.c[2];
+        if (!(dx * dx + dy * dy + dz * dz < b.r_in2)) continue;
+        float t;
+        uint32_t won;
+        if (ball_resolve(S, b, r, t, won)) {
+            r.t_max = t;
+            code |= (1u + 3u * k + won) << 8;
+        }
+        break; // balls do not overlap: the first that holds the origin is the only one
+    }
+    t_max = r.t_max;
+}
+// What the code says about the ray's hit so far: leaf slot (| kBestRare) of the ball's primitive
+// or the enclosing medium it ends in, or RT_MISS; resolved: no traversal needed.
+RT_DEV uint32_t pretest_best(const SceneDev &S, uint32_t code, bool &resolved) {
+    const uint32_t which = code & 0xffu, r = (code >> 8) & 0xffu;
+    resolved = r != 0;
+    if (r != 0 && (r - 1u) % 3u != 2u) return S.balls[(r - 1u) / 3u].best[(r - 1u) % 3u];
+    if (which == 0) return RT_MISS;
+    return (S.n_tree_prims + which - 1) | (((S.enclosing_rare >> (which - 1)) & 1u) ? kBestRare : 0u);
+}
+// counters of a resolved ray: one test per primitive of its ball, no node
+RT_DEV void count_resolved(const SceneDev &S, uint32_t code, Counters &cnt) {
+    const uint32_t r = (code >> 8) & 0xffu;
+    if (r == 0) return;
+    const BallDev &b = S.balls[(r - 1u) / 3u];
+    cnt.prims[RT_MEDIUM]++;
+    if (b.sphere >= 0) cnt.prims[RT_SPHERE]++;
+}
+
 // <BVH as Primitive>::intersect / does_intersect, shapes/src/bvh.rs:736-863, for a
 // stream of rays, with the ray shortened on every accepted hit (ties go to the
 // primitive tested later).
@@ -389,9 +491,15 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                     // Media that enclose the scene are not in the tree: every ray tests them before it
                     // starts traversing, and a hit shortens it.  A feed whose rays were tested by
                     // their producer (Feed::kPretested) hands over the outcome in L.best / L.ray.t_max.
+                    // A ray that starts inside a ball may be resolved by the ball's own primitives
+                    // (ball_resolve): it then needs no traversal at all.
                     bool occluded = false;
                     if constexpr (Feed::kPretested) {
-                        if (COUNT) cnt.prims[RT_MEDIUM] += S.n_enclosing;
+                        if (COUNT) {
+                            cnt.prims[RT_MEDIUM] += S.n_enclosing;
+                            count_resolved(S, feed.code, cnt);
+                        }
+                        occluded = (feed.code >> 8) != 0; // resolved: skip the tree
                     } else {
                         L.best = RT_MISS;
                         for (uint32_t e = 0; e < S.n_enclosing; e++) {
@@ -404,6 +512,22 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                                 L.best = slot | ((lp.kind & kRareShade) ? kBestRare : 0u);
                                 L.a0 = L.a1 = L.a2 = 0.0f;
                                 if (ANY) occluded = true;
+                            }
+                        }
+                        if constexpr (!ANY) {
+                            for (uint32_t k = 0; k < S.n_balls; k++) {
+                                const BallDev &b = S.balls[k];
+                                const float dx = L.ray.o.x - b.c[0], dy = L.ray.o.y - b.c[1], dz = L.ray.o.z - b.c[2];
+                                if (!(dx * dx + dy * dy + dz * dz < b.r_in2)) continue;
+                                float t;
+                                uint32_t won;
+                                if (ball_resolve(S, b, L.ray, t, won)) {
+                                    L.ray.t_max = t;
+                                    if (won != 2u) L.best = b.best[won];
+                                    if (COUNT) count_resolved(S, (1u + 3u * k + won) << 8, cnt);
+                                    occluded = true; // resolved: skip the tree
+                                }
+                                break;
                             }
                         }
                     }
@@ -556,31 +680,6 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
     }
     feed.finish();
     PROF(if (COUNT) cnt.p[9] += __builtin_amdgcn_s_memtime() - tp0;)
-}
-
-// The media that enclose the scene, tested by whoever makes a ray (camera rays, scattered
-// rays: all lanes of a full wave at once) instead of by the traversal that picks the ray up
-// later with a few lanes.  t_max: the ray's end after them; which: 0, or k when the ray
-// scatters in the k-th of them.  The same tests in the same order on the same ray as
-// trace_stream makes for rays that come without this.
-RT_DEV void enclosing_pretest(const SceneDev &S, const Ray &ray, float &t_max, uint32_t &which) {
-    Ray r = ray;
-    which = 0;
-    const v3 rd = mk(0.0f, 0.0f, 0.0f); // only boxes read the reciprocal direction; these are spheres
-    for (uint32_t e = 0; e < S.n_enclosing; e++) {
-        const LeafPrim lp = S.leaf[S.n_tree_prims + e];
-        float t;
-        if (medium_test(S, lp, r, rd, t)) {
-            r.t_max = t;
-            which = e + 1;
-        }
-    }
-    t_max = r.t_max;
-}
-// leaf slot (| kBestRare) of the k-th enclosing medium, or RT_MISS for 0
-RT_DEV uint32_t enclosing_best(const SceneDev &S, uint32_t which) {
-    if (which == 0) return RT_MISS;
-    return (S.n_tree_prims + which - 1) | (((S.enclosing_rare >> (which - 1)) & 1u) ? kBestRare : 0u);
 }
 
 RT_DEV Ray load_ray(const rt_ray *rays, size_t i) {
@@ -1108,13 +1207,13 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(FrameDev F, rt_camera 
 // ---- bounce queues ------------------------------------------------------------------------------
 RT_DEV void queue_push(const SceneDev &S, const Queue &q, size_t slot, const Ray &r, uint32_t local, v3 beta,
                        const Rng &rng, uint32_t gpath) {
-    if (S.n_enclosing) {
+    if (S.n_enclosing | S.n_balls) {
         float t_max;
-        uint32_t which;
+        uint32_t code;
         Ray fresh = r;
         fresh.t_max = kInf; // every queued ray starts unbounded
-        enclosing_pretest(S, fresh, t_max, which);
-        q.e[slot] = make_uint2(__float_as_uint(t_max), which);
+        pretest(S, fresh, t_max, code);
+        q.e[slot] = make_uint2(__float_as_uint(t_max), code);
     }
     q.a[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
     q.b[slot] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(local));
@@ -1440,6 +1539,7 @@ struct BounceFeed {
     // direct lighting: the shadow rays this bounce makes (sub-queue and tail as for qout)
     ShadowQueue sq;
     uint32_t *stail;
+    uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     PROF(unsigned long long prof_take = 0; unsigned long long prof_load = 0; unsigned long long prof_park = 0;)
     RT_DEV bool more() const { return blocks.more(); }
@@ -1606,15 +1706,18 @@ struct BounceFeed {
             if (next != kNone) {
                 const float4 qa = qin.a[in_base + next], qb = qin.b[in_base + next];
                 uint2 qe = make_uint2(__float_as_uint(kInf), 0u);
-                if (S.n_enclosing) qe = qin.e[in_base + next];
+                if (S.n_enclosing | S.n_balls) qe = qin.e[in_base + next];
                 PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
                 if (__float_as_uint(qb.w) != kDead) {
                     L.ray.o = mk(qa.x, qa.y, qa.z);
                     L.ray.time = qa.w;
                     L.ray.d = mk(qb.x, qb.y, qb.z);
-                    // what the ray's producer found in the media that enclose the scene
+                    // what the ray's producer found in the media that enclose the scene and, for a
+                    // ray that starts inside a ball, in the ball
                     L.ray.t_max = __uint_as_float(qe.x);
-                    L.best = enclosing_best(S, qe.y);
+                    bool resolved;
+                    L.best = pretest_best(S, qe.y, resolved);
+                    code = qe.y;
                     L.a0 = L.a1 = L.a2 = 0.0f;
                     entry = next;
                     L.has_ray = true;
@@ -1761,6 +1864,10 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 #ifndef RT_LOOP_REFILL_LANES
 #define RT_LOOP_REFILL_LANES 40
 #endif
+// lanes that must want it for a shading batch to go round again in place (LoopFeed::shade_batch)
+#ifndef RT_AGAIN_LANES
+#define RT_AGAIN_LANES 32
+#endif
 constexpr uint32_t kRingSlots = 512;
 constexpr size_t kLoopParkBytes = 2 * kParkSlots * 5 * 16, kLoopLaneBytes = 64 * 2 * 16,
                  kLoopRingBytes = kRingSlots * 4 * 16;
@@ -1784,6 +1891,8 @@ struct LoopFeed {
     uint32_t *save;
     uint32_t parked[2];
     uint32_t ring_head, ring_count, turns, turn_limit;
+    uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
+    Counters *cnt = nullptr; // counting launches: where segments shaded without a traversal are counted
 #ifdef RT_TAIL_PROBE
     unsigned long long probe_dry = 0; // clock when this wave first found the queue read out
     uint32_t probe_held = 0, probe_turns_dry = 0, probe_batches = 0, probe_batch_fill = 0;
@@ -1823,22 +1932,36 @@ struct LoopFeed {
             depth = __float_as_uint(p4.w);
             rng.state = ((uint64_t)__float_as_uint(p4.x) << 32) | __float_as_uint(p3.w);
             rng.inc = (((seed << 32) + gpath) << 1) | 1u;
-            alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && depth < last;
         }
-        // survivors join the ring as segments of the next bounce
-        const uint64_t mask = __ballot(alive);
-        if (mask) {
-            if (alive) {
+        // Survivors join the ring as segments of the next bounce -- unless the maker's tests
+        // (pretest) already decide the next segment's hit: a ray inside a ball.  If the plain
+        // shader covers that hit the lane shades it here and now, again and again while that
+        // holds: a path scattering inside a fog-filled ball runs from shading to shading without
+        // a queue entry, a lane of the traversal or a parking slot in between.
+        bool run = lane < count;
+        for (;;) {
+            alive = false;
+            if (run) alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && depth < last;
+            // the new ray against the media that enclose the scene and its ball, here where the
+            // whole batch works: t_max after them, and what was found (the pretest's code)
+            float t_max = kInf;
+            uint32_t which = 0;
+            if (alive && (S.n_enclosing | S.n_balls)) {
+                Ray fresh = P.ray;
+                fresh.t_max = kInf;
+                pretest(S, fresh, t_max, which);
+            }
+            bool resolved = false;
+            uint32_t next_best = RT_MISS;
+            if (PLAIN && alive) next_best = pretest_best(S, which, resolved);
+            bool again = PLAIN && alive && resolved && next_best != RT_MISS && (next_best & kBestRare) == 0;
+            // only while most of the wave takes part: a few long paths must not hold the others
+            // (and the wave's traversing lanes) through dozens of nearly empty rounds
+            if ((uint32_t)__popcll(__ballot(again)) < (uint32_t)RT_AGAIN_LANES) again = false;
+            const bool queued = alive && !again;
+            const uint64_t mask = __ballot(queued);
+            if (queued) {
                 float4 *e = ring + (size_t)((ring_head + ring_count + lane_rank(mask)) % kRingSlots) * 4;
-                // the new ray against the media that enclose the scene, here where the whole
-                // batch works: t_max after them, and which of them it scatters in
-                float t_max = kInf;
-                uint32_t which = 0;
-                if (S.n_enclosing) {
-                    Ray fresh = P.ray;
-                    fresh.t_max = kInf;
-                    enclosing_pretest(S, fresh, t_max, which);
-                }
                 e[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
                 e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
                 e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
@@ -1847,7 +1970,7 @@ struct LoopFeed {
             }
             ring_count += (uint32_t)__popcll(mask);
             // segments per bounce, where the per-bounce kernels keep their queue sizes
-            uint64_t todo = mask;
+            uint64_t todo = __ballot(alive);
             while (todo) {
                 const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
                 const uint32_t dd = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)leader);
@@ -1855,6 +1978,18 @@ struct LoopFeed {
                 if (lane == leader)
                     atomicAdd(&counts[((size_t)(dd + 1) * kShards + shard) * kCountStride], (uint32_t)__popcll(same));
                 todo &= ~same;
+            }
+            run = again;
+            if (__ballot(run) == 0) break;
+            if (run) {
+                if (cnt) { // what the traversal counts for a resolved ray
+                    cnt->prims[RT_MEDIUM] += S.n_enclosing;
+                    count_resolved(S, which, *cnt);
+                }
+                depth++;
+                P.ray.t_max = t_max;
+                P.best = next_best;
+                P.a0 = P.a1 = P.a2 = 0.0f;
             }
         }
     }
@@ -1980,7 +2115,7 @@ struct LoopFeed {
                 if (__float_as_uint(qb.w) != kDead) {
                     qc = qin.c[in_base + next];
                     const uint2 d2 = qin.d[in_base + next];
-                    if (S.n_enclosing) {
+                    if (S.n_enclosing | S.n_balls) {
                         const uint2 qe = qin.e[in_base + next];
                         t0 = __uint_as_float(qe.x);
                         which = qe.y;
@@ -1994,7 +2129,9 @@ struct LoopFeed {
                 L.ray.time = qa.w;
                 L.ray.d = mk(qb.x, qb.y, qb.z);
                 L.ray.t_max = t0;
-                L.best = enclosing_best(S, which);
+                bool resolved;
+                L.best = pretest_best(S, which, resolved);
+                code = which;
                 L.a0 = L.a1 = L.a2 = 0.0f;
                 lane_c[lane] = qc;
                 lane_d[lane] = qd;
@@ -2054,6 +2191,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   reinterpret_cast<float4 *>(mine + kLoopParkBytes + kLoopLaneBytes),
                   reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
                   {0u, 0u}, 0u, 0u, 0u, turn_limit};
+    if (COUNT) feed.cnt = &cnt;
     feed.blocks.start();
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);

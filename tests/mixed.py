@@ -68,3 +68,48 @@ def mixed_scene(seed=1, n_each=40, with_normals=True, with_media=True):
                  xform=s.add_xform(translate((4.0, 0.0, -3.0)) @ rotate_y(30.0)))
     s.add_medium(0.01, iso, sphere=((0.0, 0.0, 0.0), 40.0))
     return s
+
+
+def ball_scene(seed=1, n_each=20):
+    """The mixed scene's surfaces plus fog balls away from them: A a glass shell filled with fog,
+    B fog alone, C shell + fog with a small sphere closer to it than the safety distance (not a
+    ball for the short cut), D the same with the sphere just far enough, all inside a thin fog
+    that encloses the scene.  Returns (scene, centres and radii of A..D)."""
+    s = mixed_scene(seed=seed, n_each=n_each, with_media=False)
+    glass = s.dielectric(1.5)
+    iso = s.isotropic((0.3, 0.5, 0.8))
+    grey = s.lambertian((0.6, 0.6, 0.6))
+    balls = [((30.0, 0.0, 0.0), 5.0), ((-30.0, 5.0, 0.0), 4.0), ((0.0, 30.0, 0.0), 5.0), ((0.0, -30.0, 0.0), 5.0)]
+    s.add_sphere(*balls[0], glass)
+    s.add_medium(0.5, iso, sphere=balls[0])
+    s.add_medium(0.3, iso, sphere=balls[1])
+    s.add_medium(0.5, iso, sphere=balls[2])
+    s.add_sphere(*balls[2], glass)
+    s.add_sphere((0.0, 30.0, 5.0 + 0.004 + 0.5), 0.5, grey)
+    s.add_sphere(*balls[3], glass)
+    s.add_medium(0.5, iso, sphere=balls[3])
+    s.add_sphere((0.0, -30.0, 5.0 + 0.05 + 0.5), 0.5, grey)
+    s.add_medium(0.002, iso, sphere=((0.0, 0.0, 0.0), 200.0))
+    return s, balls
+
+
+def rays_inside(balls, n, seed):
+    """n rays per ball that start inside it (uniform in the ball, some very near its surface),
+    directions uniform, a third with a finite end."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for c, r in balls:
+        rays = np.zeros(n, dtype=abi.ray_dtype)
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        u = rng.random(n) ** (1.0 / 3.0)
+        u[: n // 8] = 1.0 - rng.random(n // 8) * 4e-3  # around the margin of the inside test
+        o = np.asarray(c) + d * (u * r)[:, None]
+        d2 = rng.normal(size=(n, 3))
+        d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        rays["o"] = o.astype(np.float32)
+        rays["d"] = (d2 * rng.choice([1.0, 1.0, 3.5, 0.2], n)[:, None]).astype(np.float32)
+        rays["t_max"] = np.where(rng.random(n) < 0.33, rng.random(n) * 3 * r, np.inf).astype(np.float32)
+        rays["time"] = rng.random(n).astype(np.float32)
+        out.append(rays)
+    return np.concatenate(out)
