@@ -348,7 +348,14 @@ typedef struct rt_scene rt_scene;
  * not given to the tree: every ray would meet them.  Up to four of them, in primitive order,
  * are tested once per ray before its traversal, and a hit shortens the ray like any other;
  * rt_scene_info lists them.  The reference has no media; its tree is built over exactly the
- * primitives it knows. */
+ * primitives it knows.
+ * Balls: a medium bounded by a sphere (no instance transform) that no other primitive comes
+ * near -- alone or inside one sphere primitive of exactly the same centre and radius, the glass
+ * ball filled with fog of test/week.toml -- stays in the tree, but a ray that starts well inside
+ * it (|o - c| < 0.998 r) is resolved by the ball's own primitives without a walk through the
+ * tree whenever they decide its closest hit; the results are those of the walk, bit for bit,
+ * and the traversal counters then take one test per primitive of the ball and no node.
+ * rt_scene_info.n_balls says how many were found (at most four are used). */
 int rt_scene_create(const rt_scene_desc *desc, const rt_build_opts *opts, rt_scene **out);
 
 /* Drop for BVH. Frees host and device memory on every device used. */
