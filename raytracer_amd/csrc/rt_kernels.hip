@@ -1864,10 +1864,6 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
 #ifndef RT_LOOP_REFILL_LANES
 #define RT_LOOP_REFILL_LANES 40
 #endif
-// lanes that must want it for a shading batch to go round again in place (LoopFeed::shade_batch)
-#ifndef RT_AGAIN_LANES
-#define RT_AGAIN_LANES 32
-#endif
 constexpr uint32_t kRingSlots = 512;
 constexpr size_t kLoopParkBytes = 2 * kParkSlots * 5 * 16, kLoopLaneBytes = 64 * 2 * 16,
                  kLoopRingBytes = kRingSlots * 4 * 16;
@@ -1914,6 +1910,9 @@ struct LoopFeed {
             probe_batch_fill += count;
         }
 #endif
+        // records parked by other lanes (also by the batch before this one) are read here
+        asm volatile("" ::: "memory");
+        __threadfence_block();
         if (lane < count) {
             const float4 *r = park + (size_t)(first + lane) * 5;
             const float4 p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3], p4 = r[4];
@@ -1933,64 +1932,63 @@ struct LoopFeed {
             rng.state = ((uint64_t)__float_as_uint(p4.x) << 32) | __float_as_uint(p3.w);
             rng.inc = (((seed << 32) + gpath) << 1) | 1u;
         }
-        // Survivors join the ring as segments of the next bounce -- unless the maker's tests
-        // (pretest) already decide the next segment's hit: a ray inside a ball.  If the plain
-        // shader covers that hit the lane shades it here and now, again and again while that
-        // holds: a path scattering inside a fog-filled ball runs from shading to shading without
-        // a queue entry, a lane of the traversal or a parking slot in between.
-        bool run = lane < count;
-        for (;;) {
-            alive = false;
-            if (run) alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && depth < last;
-            // the new ray against the media that enclose the scene and its ball, here where the
-            // whole batch works: t_max after them, and what was found (the pretest's code)
-            float t_max = kInf;
-            uint32_t which = 0;
-            if (alive && (S.n_enclosing | S.n_balls)) {
-                Ray fresh = P.ray;
-                fresh.t_max = kInf;
-                pretest(S, fresh, t_max, which);
+        if (lane < count) alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && depth < last;
+        // the new ray against the media that enclose the scene and its ball, here where the
+        // whole batch works: t_max after them, and what was found (the pretest's code)
+        float t_max = kInf;
+        uint32_t which = 0;
+        if (alive && (S.n_enclosing | S.n_balls)) {
+            Ray fresh = P.ray;
+            fresh.t_max = kInf;
+            pretest(S, fresh, t_max, which);
+        }
+        // Survivors join the ring as segments of the next bounce -- unless the pretest already
+        // decides the next segment's hit (a ray inside a ball).  That segment is a finished one:
+        // it needs no lane of the traversal.  If the plain shader covers its hit it goes straight
+        // back to the parking list this batch came from, whose slots are free again (all lanes
+        // have read their records), to be shaded with the next full batch: a path scattering
+        // inside a fog-filled ball runs from shading to shading without ring entry or lane.
+        // (Shading it at once, in this batch, was tried too: as long as at least N lanes wanted
+        // to, for N = 32 ... 56; the fuller batches of the parking list won at every N.)
+        bool resolved = false;
+        uint32_t next_best = RT_MISS;
+        if (PLAIN && alive) next_best = pretest_best(S, which, resolved);
+        const bool done = PLAIN && alive && resolved && next_best != RT_MISS && (next_best & kBestRare) == 0;
+        const uint64_t m_done = __ballot(done);
+        if (done) {
+            float4 *r = park + (size_t)(parked[0] + lane_rank(m_done)) * 5;
+            r[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
+            r[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
+            r[2] = make_float4(__uint_as_float(next_best), 0.0f, 0.0f, 0.0f);
+            r[3] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
+            r[4] = make_float4(__uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float(gpath),
+                               __uint_as_float(local), __uint_as_float(depth + 1));
+            if (cnt) { // what the traversal counts for a resolved ray
+                cnt->prims[RT_MEDIUM] += S.n_enclosing;
+                count_resolved(S, which, *cnt);
             }
-            bool resolved = false;
-            uint32_t next_best = RT_MISS;
-            if (PLAIN && alive) next_best = pretest_best(S, which, resolved);
-            bool again = PLAIN && alive && resolved && next_best != RT_MISS && (next_best & kBestRare) == 0;
-            // only while most of the wave takes part: a few long paths must not hold the others
-            // (and the wave's traversing lanes) through dozens of nearly empty rounds
-            if ((uint32_t)__popcll(__ballot(again)) < (uint32_t)RT_AGAIN_LANES) again = false;
-            const bool queued = alive && !again;
-            const uint64_t mask = __ballot(queued);
-            if (queued) {
-                float4 *e = ring + (size_t)((ring_head + ring_count + lane_rank(mask)) % kRingSlots) * 4;
-                e[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
-                e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
-                e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
-                e[3] = make_float4(__uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float(gpath),
-                                   __uint_as_float(local), __uint_as_float((depth + 1) | (which << 8)));
-            }
-            ring_count += (uint32_t)__popcll(mask);
-            // segments per bounce, where the per-bounce kernels keep their queue sizes
-            uint64_t todo = __ballot(alive);
-            while (todo) {
-                const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-                const uint32_t dd = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)leader);
-                const uint64_t same = __ballot(alive && depth == dd);
-                if (lane == leader)
-                    atomicAdd(&counts[((size_t)(dd + 1) * kShards + shard) * kCountStride], (uint32_t)__popcll(same));
-                todo &= ~same;
-            }
-            run = again;
-            if (__ballot(run) == 0) break;
-            if (run) {
-                if (cnt) { // what the traversal counts for a resolved ray
-                    cnt->prims[RT_MEDIUM] += S.n_enclosing;
-                    count_resolved(S, which, *cnt);
-                }
-                depth++;
-                P.ray.t_max = t_max;
-                P.best = next_best;
-                P.a0 = P.a1 = P.a2 = 0.0f;
-            }
+        }
+        parked[0] += (uint32_t)__popcll(m_done);
+        const bool queued = alive && !done;
+        const uint64_t mask = __ballot(queued);
+        if (queued) {
+            float4 *e = ring + (size_t)((ring_head + ring_count + lane_rank(mask)) % kRingSlots) * 4;
+            e[0] = make_float4(P.ray.o.x, P.ray.o.y, P.ray.o.z, P.ray.time);
+            e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
+            e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
+            e[3] = make_float4(__uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float(gpath),
+                               __uint_as_float(local), __uint_as_float((depth + 1) | (which << 8)));
+        }
+        ring_count += (uint32_t)__popcll(mask);
+        // segments per bounce, where the per-bounce kernels keep their queue sizes
+        uint64_t todo = __ballot(alive);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+            const uint32_t dd = (uint32_t)__builtin_amdgcn_readlane((int)depth, (int)leader);
+            const uint64_t same = __ballot(alive && depth == dd);
+            if (lane == leader)
+                atomicAdd(&counts[((size_t)(dd + 1) * kShards + shard) * kCountStride], (uint32_t)__popcll(same));
+            todo &= ~same;
         }
     }
 
