@@ -28,7 +28,11 @@ static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r
 static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
-static inline v3 v3_div(v3 a, float s) { return v3_make(a.x / s, a.y / s, a.z / s); }
+/* Div<T> for Vector3 / Point3 (vector3.rs:260-264, point3.rs:271-275): one reciprocal, three products */
+static inline v3 v3_div(v3 a, float s) {
+    const float inv = 1.0f / s;
+    return v3_make(a.x * inv, a.y * inv, a.z * inv);
+}
 static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
 static inline v3 v3_abs(v3 a) { return v3_make(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 /* dot: ((x*x + y*y) + z*z), geometry/src/vector3.rs dot() order */

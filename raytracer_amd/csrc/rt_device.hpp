@@ -142,7 +142,11 @@ RT_DEV v3 mk(float x, float y, float z) { return v3{x, y, z}; }
 RT_DEV v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_DEV v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_DEV v3 operator*(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-RT_DEV v3 operator/(v3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// Div<T> for Vector3 / Point3 (vector3.rs:260-264, point3.rs:271-275): one reciprocal, three products
+RT_DEV v3 operator/(v3 a, float s) {
+    const float inv = 1.0f / s;
+    return mk(a.x * inv, a.y * inv, a.z * inv);
+}
 RT_DEV v3 operator-(v3 a) { return mk(-a.x, -a.y, -a.z); }
 RT_DEV v3 vabs(v3 a) { return mk(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 RT_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
