@@ -2144,14 +2144,27 @@ struct LoopFeed {
         return fresh;
     }
 
-    // nothing in the lanes, the ring or the queue: the paths parked in incomplete batches go on
+    // Nothing in the lanes, the ring or the queue: the paths parked in incomplete batches go on.
+    // One batch per list and call, so that survivors which need a traversal get their lanes at once
+    // instead of waiting in the ring while the resolved ones (which come straight back to the
+    // list) are followed to their ends: every path has dozens of generations to go, and what
+    // counts at the end of a launch is that they all advance side by side.
     RT_DEV bool drain() {
         asm volatile("" ::: "memory");
         __threadfence_block();
-        shade_lists(1);
+        if (parked[0] != 0) {
+            const uint32_t count = parked[0] < 64u ? parked[0] : 64u;
+            parked[0] -= count;
+            shade_batch<true>(parked[0], count);
+        }
+        if (parked[1] != 0) {
+            const uint32_t count = parked[1] < 64u ? parked[1] : 64u;
+            parked[1] -= count;
+            shade_batch<false>(kParkSlots + parked[1], count);
+        }
         asm volatile("" ::: "memory");
         __threadfence_block();
-        return ring_count != 0;
+        return (ring_count | parked[0] | parked[1]) != 0;
     }
     RT_DEV void finish() {}
 };
