@@ -466,10 +466,11 @@ static void find_enclosing(orc_scene *s, const aabb *bounds) {
  * 0.002 x (radius + half the diagonal of the other's box).  A ray that starts inside such a ball
  * (|o - c|^2 < (0.998 r)^2) meets everything else only after it has left the ball, so its
  * closest hit is decided by the ball's own primitives: see ball_resolve.  The first
- * ORC_MAX_BALLS balls in primitive order are kept.  Same rule, same arithmetic in the library. */
+ * ORC_MAX_BALLS balls in primitive order are kept, out of the first 64 such media.  Same rule, same arithmetic in the library. */
 static void find_balls(orc_scene *s, const aabb *bounds) {
     s->n_balls = 0;
     if (getenv("ORC_NO_BALLS")) return; /* tests compare results with and without the short cut */
+    uint32_t examined = 0;
     for (uint32_t i = 0; i < s->n_prims && s->n_balls < ORC_MAX_BALLS; i++) {
         const rt_prim_ref *p = &s->prims[i];
         if ((p->kind & 0xffu) != RT_MEDIUM) continue;
@@ -480,6 +481,7 @@ static void find_balls(orc_scene *s, const aabb *bounds) {
         if (skip) continue;
         const rt_sphere *sp = &s->spheres[m->boundary_index];
         if (!(sp->r > 0.0f)) continue;
+        if (++examined > 64) break; /* every candidate is held against every primitive: keep that bounded */
         orc_ball b;
         memcpy(b.c, sp->c, sizeof b.c);
         b.r = sp->r;

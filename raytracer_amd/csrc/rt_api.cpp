@@ -324,7 +324,7 @@ std::vector<uint32_t> find_enclosing(const rt_scene &s, const std::vector<Aabb> 
 // 0.002 x (radius + half the diagonal of the other's box).  A ray that starts inside such a ball
 // (|o - c|^2 < (0.998 r)^2) meets everything else only after it has left the ball, so its
 // closest hit is decided by the ball's own primitives (ball_resolve in rt_kernels.hip).  The
-// first kMaxBalls balls in primitive order are kept.  RT355_NO_BALLS=1 finds none (a test hook:
+// first kMaxBalls balls in primitive order are kept, out of the first 64 such media.  RT355_NO_BALLS=1 finds none (a test hook:
 // results must not depend on it).
 std::vector<rt_scene::Ball> find_balls(const rt_scene &s, const std::vector<Aabb> &bounds) {
     std::vector<rt_scene::Ball> out;
@@ -334,6 +334,7 @@ std::vector<rt_scene::Ball> find_balls(const rt_scene &s, const std::vector<Aabb
             if (e == i) return true;
         return false;
     };
+    uint32_t examined = 0;
     for (size_t i = 0; i < s.prims.size() && out.size() < rt::kMaxBalls; i++) {
         const rt_prim_ref &p = s.prims[i];
         if ((p.kind & 0xffu) != RT_MEDIUM) continue;
@@ -341,6 +342,7 @@ std::vector<rt_scene::Ball> find_balls(const rt_scene &s, const std::vector<Aabb
         if (m.boundary_kind != RT_BOUNDARY_SPHERE || m.xform != 0 || is_enclosing(i)) continue;
         const rt_sphere &sp = s.spheres[m.boundary_index];
         if (!(sp.r > 0.0f)) continue;
+        if (++examined > 64) break; // every candidate is held against every primitive: keep that bounded
         rt_scene::Ball b;
         b.medium = (uint32_t)i;
         b.sphere = -1;
