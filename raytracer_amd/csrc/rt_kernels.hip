@@ -122,7 +122,7 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
 #define PROF(...)
 #endif
 
-// Cost probes (-DRT_DOUBLE_SHADE / _PRIM / _SLAB): the named piece runs a second time on
+// Cost probes (-DRT_DOUBLE_SHADE / _PRIM / _SLAB / _PRETEST): the named piece runs a second time on
 // opaque copies of its inputs with its results thrown away, so that counter deltas between
 // builds measure that piece.  Never defined in the shipped library.
 RT_DEV float opaque(float x) {
@@ -1212,6 +1212,17 @@ RT_DEV void queue_push(const SceneDev &S, const Queue &q, size_t slot, const Ray
         uint32_t code;
         Ray fresh = r;
         fresh.t_max = kInf; // every queued ray starts unbounded
+#ifdef RT_DOUBLE_PRETEST
+        {
+            Ray again = fresh;
+            again.o.x = opaque(again.o.x);
+            float t2;
+            uint32_t c2;
+            pretest(S, again, t2, c2);
+            float sink = t2 + __uint_as_float(c2);
+            asm volatile("" ::"v"(sink));
+        }
+#endif
         pretest(S, fresh, t_max, code);
         q.e[slot] = make_uint2(__float_as_uint(t_max), code);
     }
