@@ -69,6 +69,19 @@ class SceneBuilder {
         gspheres_.push_back(s);
         return push(RT_GSPHERE | (reverse_orientation ? RT_PRIM_REVERSE : 0u), uint32_t(gspheres_.size() - 1), mat, 0);
     }
+    // Constant-density media (a Volume of the scene files): scattering with the phase function of
+    // `mat` (RT_MAT_ISOTROPIC) inside a sphere, or inside a box with an optional instance transform
+    uint32_t add_medium_sphere(std::array<float, 3> c, float r, float density, uint32_t mat = 0) {
+        spheres_.push_back({{c[0], c[1], c[2]}, r});
+        media_.push_back({RT_BOUNDARY_SPHERE, uint32_t(spheres_.size() - 1), 0u, density});
+        return push(RT_MEDIUM, uint32_t(media_.size() - 1), mat, 0);
+    }
+    uint32_t add_medium_box(std::array<float, 3> lo, std::array<float, 3> hi, float density, uint32_t mat = 0,
+                            uint32_t xf = 0) {
+        boxes_.push_back({{lo[0], lo[1], lo[2]}, 0.f, {hi[0], hi[1], hi[2]}, 0.f});
+        media_.push_back({RT_BOUNDARY_BOX, uint32_t(boxes_.size() - 1), xf, density});
+        return push(RT_MEDIUM, uint32_t(media_.size() - 1), mat, 0);
+    }
     void background(float r, float g, float b) { bg_ = {r, g, b}; }
 
     rt_scene_desc desc() const {
@@ -81,6 +94,7 @@ class SceneBuilder {
         d.boxes = boxes_.data();
         d.gspheres = gspheres_.data();
         d.xforms = xforms_.data();
+        d.media = media_.data();
         d.materials = materials_.data();
         d.textures = textures_.data();
         d.n_prims = uint32_t(prims_.size());
@@ -91,6 +105,7 @@ class SceneBuilder {
         d.n_boxes = uint32_t(boxes_.size());
         d.n_gspheres = uint32_t(gspheres_.size());
         d.n_xforms = uint32_t(xforms_.size());
+        d.n_media = uint32_t(media_.size());
         d.n_materials = uint32_t(materials_.size());
         d.n_textures = uint32_t(textures_.size());
         d.background[0] = bg_[0], d.background[1] = bg_[1], d.background[2] = bg_[2];
@@ -110,6 +125,7 @@ class SceneBuilder {
     std::vector<rt_box> boxes_;
     std::vector<rt_gsphere> gspheres_;
     std::vector<rt_xform> xforms_;
+    std::vector<rt_medium> media_;
     std::vector<rt_material> materials_;
     std::vector<rt_texture> textures_;
     std::array<float, 3> bg_{0.f, 0.f, 0.f};

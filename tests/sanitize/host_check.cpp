@@ -50,6 +50,26 @@ static void fill(rt355::SceneBuilder &b, int n) {
         }
         }
     }
+    if (n >= 5) {
+        // media: a thin fog around everything (kept out of the tree), a fog ball inside a glass
+        // shell away from the rest (a ball: rays from inside skip the tree), one without a shell,
+        // one with a neighbour too close to count, and a box of smoke
+        rt_material iso{};
+        iso.kind = RT_MAT_ISOTROPIC;
+        iso.texture = t;
+        const uint32_t fog = b.material(iso);
+        rt_material glass{};
+        glass.kind = RT_MAT_DIELECTRIC;
+        glass.ior = 1.5f;
+        const uint32_t gl = b.material(glass);
+        b.add_medium_sphere({0, 0, 0}, 200.0f, 0.002f, fog);
+        b.add_sphere({40, 0, 0}, 5.0f, gl);
+        b.add_medium_sphere({40, 0, 0}, 5.0f, 0.5f, fog);
+        b.add_medium_sphere({-40, 0, 0}, 4.0f, 0.3f, fog);
+        b.add_medium_sphere({0, 40, 0}, 5.0f, 0.5f, fog);
+        b.add_sphere({0, 40, 5.504f}, 0.5f, mat);
+        b.add_medium_box({20, 20, 20}, {24, 23, 25}, 0.2f, fog);
+    }
     b.background(0.5f, 0.6f, 0.9f);
 }
 
@@ -74,19 +94,27 @@ int main() {
             CHECK(rt_scene_create(&d, &o, &s) == RT_OK);
             rt_scene_info info{};
             CHECK(rt_scene_get_info(s, &info) == RT_OK);
+            CHECK(n < 5 || (info.n_enclosing == 1 && info.n_balls == 2));
             std::vector<rt_linear_node> nodes(info.n_nodes ? info.n_nodes : 1);
             std::vector<uint32_t> order(info.n_prims ? info.n_prims : 1);
             CHECK(rt_scene_get_nodes(s, nodes.data(), nodes.size()) >= 0);
             CHECK(rt_scene_get_prim_order(s, order.data(), order.size()) >= 0);
             orc_scene *os = nullptr;
             CHECK(orc_scene_create(&d, &o, &os) == RT_OK);
+            rt_scene_info oinfo{};
+            CHECK(orc_scene_get_info(os, &oinfo) == RT_OK && oinfo.n_balls == info.n_balls &&
+                  oinfo.n_enclosing == info.n_enclosing);
             // same tree on both sides
             std::vector<rt_linear_node> onodes(nodes.size());
             CHECK(orc_scene_get_nodes(os, onodes.data(), onodes.size()) >= 0);
             CHECK(info.n_nodes == 0 || memcmp(nodes.data(), onodes.data(), info.n_nodes * sizeof(rt_linear_node)) == 0);
             std::vector<rt_ray> rays(2000);
+            size_t k = 0;
             for (auto &r : rays) {
                 r.o[0] = frand() * 30 - 15; r.o[1] = frand() * 30 - 15; r.o[2] = frand() * 30 - 15;
+                if (k++ % 4 == 0) { // a quarter start inside the balls
+                    r.o[0] = (k % 8 < 4 ? 40.0f : -40.0f) + frand() * 4 - 2; r.o[1] = frand() * 4 - 2; r.o[2] = frand() * 4 - 2;
+                }
                 r.d[0] = frand() - 0.5f; r.d[1] = frand() - 0.5f; r.d[2] = frand() - 0.5f;
                 r.t_max = INFINITY;
                 r.time = frand();
