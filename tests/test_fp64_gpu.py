@@ -58,3 +58,27 @@ def test_hip_matches_fp64_on_the_benchmark_scenes(scene_cache, name):
     assert clear.mean() > 0.8, clear.mean()
     out = fp64_ref.compare(hits[keep], best, clear, **TOL)
     assert out["n_hits"] > 2000, out
+
+
+def test_hip_matches_fp64_from_inside_the_balls():
+    """Rays that start inside fog balls take the short cut that skips the tree.  Where the fog does
+    not scatter them their hit is the shell from inside, or -- fog without a shell, or a ray
+    that ends first -- whatever surface lies beyond: the float64 intersector, which knows nothing of
+    balls, must agree."""
+    from tests.mixed import ball_scene, rays_inside
+    sd, balls = ball_scene(seed=11)
+    fr = sd.freeze()
+    g = lib.Scene(fr)
+    assert g.info().n_balls == 3
+    rays = rays_inside(balls, 8000, 11)
+    hits = g.intersect(rays)
+    kinds = fr._keep["prims"]["kind"] & 0xFF
+    medium_hit = (hits["prim"] != abi.RT_MISS) & (kinds[np.minimum(hits["prim"], len(kinds) - 1)] == abi.RT_MEDIUM)
+    keep = ~medium_hit
+    assert keep.sum() > 4000
+    f64 = fp64_ref.Fp64Scene(fr)
+    best = f64.closest(rays[keep])
+    clear = fp64_ref.clear_rays(f64, rays[keep], best)
+    assert clear.mean() > 0.8, clear.mean()
+    out = fp64_ref.compare(hits[keep], best, clear, **TOL)
+    assert out["n_hits"] > 2000, out
