@@ -523,7 +523,10 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                                 uint32_t won;
                                 if (ball_resolve(S, b, L.ray, t, won)) {
                                     L.ray.t_max = t;
-                                    if (won != 2u) L.best = b.best[won];
+                                    if (won != 2u) {
+                                        L.best = b.best[won];
+                                        L.a0 = L.a1 = L.a2 = 0.0f;
+                                    }
                                     if (COUNT) count_resolved(S, (1u + 3u * k + won) << 8, cnt);
                                     occluded = true; // resolved: skip the tree
                                 }
