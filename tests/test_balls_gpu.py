@@ -3,6 +3,8 @@
 batches of the one-launch kernel go round again in place for them.  Everything must equal the
 oracle bit for bit -- hits, any-hit, counters, frames, statistics -- and must not depend on the
 short cut being there (RT355_NO_BALLS)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("nodes", ["lds", "global"])
-@pytest.mark.parametrize("seed,max_prims,split", [(3, 4, abi.RT_SPLIT_SAH), (4, 1, abi.RT_SPLIT_HLBVH)])
+@pytest.mark.parametrize("seed,max_prims,split", [(3, 4, abi.RT_SPLIT_SAH), (4, 1, abi.RT_SPLIT_HLBVH)] +
+                         # a longer soak on request: RT355_SWEEP_EXTRA=<n> more seeds
+                         [(s, 1 + s % 7, s % 4) for s in range(100, 100 + int(os.environ.get("RT355_SWEEP_EXTRA", "0")))])
 def test_rays_from_inside_the_balls(monkeypatch, nodes, seed, max_prims, split):
     import torch
     if nodes == "global":

@@ -2,6 +2,8 @@
 method, node source, number of stack levels in LDS and ray set, and compares the HIP path with
 the oracle bit for bit (closest hit, any hit, traversal counters, a small frame with and without
 direct lighting).  The cases are few and fixed (seeds below), so a failure names its case."""
+import os
+
 import numpy as np
 import pytest
 
@@ -62,6 +64,8 @@ def _drawn(seed):
 
 
 CASES += [_drawn(seed) for seed in range(109, 133)]
+# a longer soak on request: RT355_SWEEP_EXTRA=<n> draws n more cases
+CASES += [_drawn(seed) for seed in range(1000, 1000 + int(os.environ.get("RT355_SWEEP_EXTRA", "0")))]
 
 
 @pytest.mark.parametrize("seed,n_each,max_prims,split,nodes,stack_lds", CASES)
