@@ -116,12 +116,15 @@ int orc_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, orc_scen
     }
     /* lights for direct lighting: plain rectangles with a solid-colour DiffuseLight */
     s->lights = (uint32_t *)calloc(d->n_prims ? d->n_prims : 1, sizeof *s->lights);
+    s->is_light = (uint8_t *)calloc(d->n_prims ? d->n_prims : 1, 1);
     for (uint32_t i = 0; i < d->n_prims && d->n_materials && d->n_textures; i++) {
         const rt_prim_ref *p = &d->prims[i];
         if ((p->kind & 0xffu) != RT_RECT || p->xform) continue;
         const rt_material *m = &d->materials[p->material];
-        if (m->kind == RT_MAT_DIFFUSE_LIGHT && d->textures[m->texture].kind == RT_TEX_SOLID)
+        if (m->kind == RT_MAT_DIFFUSE_LIGHT && d->textures[m->texture].kind == RT_TEX_SOLID) {
             s->lights[s->n_lights++] = i;
+            s->is_light[i] = 1;
+        }
     }
     int rc = orc_build(s, opts);
     if (rc != RT_OK) { orc_scene_destroy(s); return rc; }
@@ -136,7 +139,7 @@ void orc_scene_destroy(orc_scene *s) {
     free(s->prims); free(s->spheres); free(s->msph); free(s->tri_verts); free(s->tri_uvs);
     free(s->tri_normals); free(s->rects); free(s->boxes); free(s->gsph); free(s->xforms);
     free(s->media); free(s->materials); free(s->textures); free(s->images); free(s->perlin_vec);
-    free(s->perlin_perm); free(s->nodes); free(s->order); free(s->lights);
+    free(s->perlin_perm); free(s->nodes); free(s->order); free(s->lights); free(s->is_light);
     free(s);
 }
 

@@ -74,6 +74,7 @@ struct orc_scene {
     /* lights of RT_RENDER_DIRECT_LIGHT: rectangles without instance transform whose material is a
      * DiffuseLight with a solid colour, in primitive order */
     uint32_t n_lights, *lights;
+    uint8_t *is_light; /* per primitive: in `lights` */
     /* Media that enclose the scene are kept out of the tree (see orc_build): every ray meets
      * them, so they are tested once per ray, before the traversal, in this order. */
     uint32_t n_enclosing, enclosing[ORC_MAX_ENCLOSING];

@@ -591,7 +591,10 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
         v3 dir;
         if (m->kind == RT_MAT_DIFFUSE_LIGHT) {
             v3 e = texture_value(s, m->texture, h.u, h.v, h.p);
-            if (!skip_emission) L = v3_add(L, v3_make(beta.x * e.x, beta.y * e.y, beta.z * e.z));
+            /* a light the shadow ray of the vertex before has already accounted for adds nothing;
+             * emitters the light list does not hold (spheres, boxes, transformed or textured
+             * rectangles) are reached by scattering only and keep their emission */
+            if (!(skip_emission && s->is_light[h.prim])) L = v3_add(L, v3_make(beta.x * e.x, beta.y * e.y, beta.z * e.z));
             break;
         } else if (m->kind == RT_MAT_LAMBERTIAN) {
             v3 r = random_in_unit_sphere(&rng);

@@ -503,6 +503,15 @@ int sampler_prepare(rt::FrameDev &F, uint32_t n_slots, bool by_rank, uint64_t fi
     return RT_OK;
 }
 
+// A light of RT_RENDER_DIRECT_LIGHT: a rectangle without instance transform whose material is a
+// DiffuseLight with a solid colour.
+bool is_sampled_light(const rt_scene &s, const rt_prim_ref &pr) {
+    if ((pr.kind & 0xffu) != RT_RECT || pr.xform || pr.material >= s.materials.size()) return false;
+    const rt_material &m = s.materials[pr.material];
+    return m.kind == RT_MAT_DIFFUSE_LIGHT && m.texture < s.textures.size() &&
+           s.textures[m.texture].kind == RT_TEX_SOLID;
+}
+
 // Lays the scene out for the kernels: one 64-byte record per interior node with
 // the boxes of both children, the primitive list in leaf order, and every typed
 // table re-packed in the order the leaves reference it so that a leaf's
@@ -641,6 +650,9 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     }
     for (const rt_linear_node &n : nodes)
         if (n.primitive_count) leaf[n.child_offset + n.primitive_count - 1].kind |= rt::kLastInLeaf;
+    // the lights RT_RENDER_DIRECT_LIGHT samples (is_sampled_light, the rule the table below is built by)
+    for (rt::LeafPrim &lp : leaf)
+        if (is_sampled_light(s, s.prims[lp.prim])) lp.kind |= rt::kSampledLight;
     // What the plain shader needs of every material, in one record: its kind and parameters and
     // its texture when that is a solid colour or a checker of two solid colours (the hits of any
     // other material go to the general shader, which follows the references).
@@ -687,11 +699,8 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     // DiffuseLight with a solid colour, in primitive order
     std::vector<rt::LightDev> lights;
     for (const rt_prim_ref &pr : s.prims) {
-        if ((pr.kind & 0xffu) != RT_RECT || pr.xform || pr.material >= s.materials.size()) continue;
+        if (!is_sampled_light(s, pr)) continue;
         const rt_material &m = s.materials[pr.material];
-        if (m.kind != RT_MAT_DIFFUSE_LIGHT || m.texture >= s.textures.size() ||
-            s.textures[m.texture].kind != RT_TEX_SOLID)
-            continue;
         const rt_rect &r = s.rects[pr.index];
         const rt_texture &t = s.textures[m.texture];
         lights.push_back(rt::LightDev{r.axis, r.k, r.a0, r.a1, r.b0, r.b1, 0.0f, {t.rgb[0], t.rgb[1], t.rgb[2]}, {0, 0}});
@@ -1441,6 +1450,8 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     if ((uint64_t)o->width * o->height * o->spp >= (1ull << 32))
         return fail(RT_ERR_LIMIT, "width * height * spp must stay below 2^32");
     if (s->materials.empty() && !s->prims.empty()) return fail(RT_ERR_INVALID, "scene has no materials");
+    // the path kernel carries a segment's depth in 16 bits
+    if (o->max_depth >= (1u << 16)) return fail(RT_ERR_LIMIT, "max_depth must stay below 65536");
     const uint32_t shard_count = o->shard_count ? o->shard_count : 1;
     if (o->shard_index >= shard_count) return fail(RT_ERR_INVALID, "shard index out of range");
     hipStream_t st = static_cast<hipStream_t>(stream);

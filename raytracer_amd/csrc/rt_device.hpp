@@ -32,6 +32,9 @@ constexpr uint32_t kRareShade = 0x400u;
 // LeafPrim.kind of a medium bounded by a sphere: geom is the sphere and index holds the bits
 // of -1 / density instead of a row of SceneDev::media
 constexpr uint32_t kMediumInSphere = 0x800u;
+// LeafPrim.kind: the primitive is one of the lights RT_RENDER_DIRECT_LIGHT samples (SceneDev::lights):
+// a path that sampled the lights at its previous vertex must not add this one's emission again
+constexpr uint32_t kSampledLight = 0x1000u;
 constexpr uint32_t kLeafRef = 0x80000000u; // child reference: leaf starting at primitive (ref & ~kLeafRef)
 
 struct GSphere { // derived form of rt_gsphere, 128 B

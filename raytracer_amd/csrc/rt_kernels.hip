@@ -1479,7 +1479,8 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
         sh->sampled = true;
     }
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
-        if (!(NEE && skip_emission)) add_radiance<NEE>(radiance, local, mk(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z));
+        // a light the shadow ray of the vertex before has already accounted for adds nothing
+        if (!(NEE && skip_emission && (lp.kind & kSampledLight))) add_radiance<NEE>(radiance, local, mk(beta.x * tex.x, beta.y * tex.y, beta.z * tex.z));
         alive = false;
     } else if (m.kind == RT_MAT_LAMBERTIAN) {
         dir = nf + rs;
@@ -1553,6 +1554,7 @@ struct BounceFeed {
     // direct lighting: the shadow rays this bounce makes (sub-queue and tail as for qout)
     ShadowQueue sq;
     uint32_t *stail;
+    size_t shadow_base; // first entry of the shadow sub-queue written (its own capacity, not qout's)
     uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     PROF(unsigned long long prof_take = 0; unsigned long long prof_load = 0; unsigned long long prof_park = 0;)
@@ -1577,7 +1579,7 @@ struct BounceFeed {
             if ((threadIdx.x & 63) == 0) base = atomicAdd(stail, total);
             base = __builtin_amdgcn_readfirstlane(base);
             if (sh.want) {
-                const size_t slot = out_base + base + lane_rank(mask); // same sub-queue geometry as qout
+                const size_t slot = shadow_base + base + lane_rank(mask);
                 sq.a[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, time);
                 sq.b[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, __uint_as_float(local));
                 sq.c[slot] = make_float4(sh.contrib.x, sh.contrib.y, sh.contrib.z, 0.0f);
@@ -1791,7 +1793,8 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                     bounce == last, seed, radiance,
                     reinterpret_cast<float4 *>(mine), reinterpret_cast<float2 *>(mine + 2 * kParkSlots * 16),
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u, sq,
-                    NEE ? scounts + ((size_t)bounce * kShards + shard) * kCountStride : nullptr};
+                    NEE ? scounts + ((size_t)bounce * kShards + shard) * kCountStride : nullptr,
+                    (size_t)shard * sq.cap};
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
@@ -1991,7 +1994,7 @@ struct LoopFeed {
             e[1] = make_float4(P.ray.d.x, P.ray.d.y, P.ray.d.z, t_max);
             e[2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((uint32_t)rng.state));
             e[3] = make_float4(__uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float(gpath),
-                               __uint_as_float(local), __uint_as_float((depth + 1) | (which << 8)));
+                               __uint_as_float(local), __uint_as_float((depth + 1) | (which << 16)));
         }
         ring_count += (uint32_t)__popcll(mask);
         // segments per bounce, where the per-bounce kernels keep their queue sizes
@@ -2117,9 +2120,11 @@ struct LoopFeed {
                 qc = e[2];
                 const float4 d4 = e[3];
                 t0 = qb.w;
-                which = __float_as_uint(d4.w) >> 8;
+                // depth in the low half (rt_render_dev keeps max_depth below 2^16), the pretest's
+                // 16-bit code in the high half
+                which = __float_as_uint(d4.w) >> 16;
                 qd = make_uint4(__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z),
-                                __float_as_uint(d4.w) & 0xffu);
+                                __float_as_uint(d4.w) & 0xffffu);
                 got = true;
             } else if (next != kNone) {
                 qa = qin.a[in_base + next];

@@ -93,3 +93,37 @@ def test_direct_light_converges_faster_than_the_default_estimator(scene_cache):
     plain_ref, _ = o.render(c, orc.render_opts(w, h, 64, 12, seed=9))
     err_plain = np.sqrt(((b[..., :3] - plain_ref[..., :3]) ** 2).mean())
     assert err_direct < 0.6 * err_plain, (err_direct, err_plain)  # about half; 64-spp references are noisy themselves
+
+
+def sphere_and_rect_lights(rect_emit=4.0, sphere_emit=(3.0, 2.0, 1.0)):
+    """A Lambertian floor under a rectangular light (sampled by the flag) and an emissive
+    sphere (reached by scattering only), black sky."""
+    s = SceneData()
+    s.add_rect(1, 0.0, -50.0, 50.0, -50.0, 50.0, s.lambertian((0.7, 0.7, 0.7)))
+    s.add_rect(1, 3.0, -1.0, 1.0, -0.5, 0.5, s.diffuse_light((rect_emit, rect_emit, rect_emit)))
+    s.add_sphere((1.5, 1.0, 0.5), 0.6, s.diffuse_light(sphere_emit))
+    cam = perspective_camera(24, 24, 25.0, look_at((0.0, 2.0, -6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)))
+    return s, cam
+
+
+def test_emitters_outside_the_light_list_keep_their_emission():
+    """Only the lights the flag samples may be skipped at the next vertex.  An emissive sphere is
+    not in the list: what it adds to the floor with the flag (frame with the sphere lit minus the
+    same frame, same draws, with the sphere black) must be what it adds without the flag (the
+    default estimator with the rectangle black), up to noise.  Before the rule was narrowed that
+    share was lost with the flag."""
+    w = h = 24
+    flag = abi.RT_RENDER_DIRECT_LIGHT
+
+    def render(rect_emit, sphere_emit, spp, seed, flags):
+        s, cam = sphere_and_rect_lights(rect_emit, sphere_emit)
+        return orc.OracleScene(s.freeze()).render(cam, orc.render_opts(w, h, spp, 3, seed=seed, flags=flags))
+
+    lit, st = render(4.0, (3.0, 2.0, 1.0), 1024, 5, flag)
+    dark, _ = render(4.0, (0.0, 0.0, 0.0), 1024, 5, flag)
+    alone, sa = render(0.0, (3.0, 2.0, 1.0), 1024, 6, 0)
+    assert st.occlusion_rays > 0 and sa.occlusion_rays == 0
+    floor = lit[..., :3].sum(-1) < 2.0  # not the lights themselves
+    share = (lit - dark)[floor][:, :3].mean(0)
+    want = alone[floor][:, :3].mean(0)
+    assert want.min() > 0.003 and np.abs(share / want - 1.0).max() < 0.05, (share, want)

@@ -8,7 +8,7 @@ import pytest
 from raytracer_amd import abi, lib
 from tests import orc
 from tests.mixed import mixed_scene
-from tests.test_direct_light_cpu import floor_under_light
+from tests.test_direct_light_cpu import floor_under_light, sphere_and_rect_lights
 
 pytestmark = pytest.mark.gpu
 FLAG = abi.RT_RENDER_DIRECT_LIGHT
@@ -84,3 +84,38 @@ def test_direct_light_against_the_closed_form_on_the_gpu():
     m = on_floor & (want > 0.02 * want.max())
     assert abs(got[m].sum() / want[m].sum() - 1.0) < 0.005
     assert np.abs(got[m] / want[m] - 1.0).max() < 0.12
+
+
+def test_shadow_queue_keeps_its_own_capacity():
+    """A large plain frame grows the bounce queues, a small direct-light frame then sizes the
+    shadow queue: the two capacities differ, and the shadow rays must still land in (and be read
+    from) their own sub-queues.  Both orders, on one Scene."""
+    _, cam, fr = scene_cache_free("cornell")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    big, _ = g.render(cam(256, 192), lib.render_opts(256, 192, 4, 6, seed=1))
+    w, h, spp = 64, 48, 2
+    c = cam(w, h)
+    ref, rst = o.render(c, orc.render_opts(w, h, spp, 8, seed=3, flags=FLAG))
+    got, gst = g.render(c, lib.render_opts(w, h, spp, 8, seed=3, flags=FLAG))
+    assert gst.occlusion_rays == rst.occlusion_rays > 0 and got.tobytes() == ref.tobytes()
+    # direct small, plain larger still, direct small again
+    g.render(cam(320, 256), lib.render_opts(320, 256, 4, 6, seed=1))
+    got, gst = g.render(c, lib.render_opts(w, h, spp, 8, seed=3, flags=FLAG))
+    assert gst.occlusion_rays == rst.occlusion_rays and got.tobytes() == ref.tobytes()
+
+
+def scene_cache_free(name):
+    from raytracer_amd import scenes
+    sd, cam = scenes.BUILDERS[name]()
+    return sd, cam, sd.freeze()
+
+
+def test_emissive_sphere_beside_a_sampled_light():
+    s, cam = sphere_and_rect_lights()
+    fr = s.freeze()
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w = h = 24
+    ref, rst = o.render(cam, orc.render_opts(w, h, 16, 4, seed=5, flags=FLAG))
+    got, gst = g.render(cam, lib.render_opts(w, h, 16, 4, seed=5, flags=FLAG))
+    assert gst.occlusion_rays == rst.occlusion_rays > 0 and gst.segments == rst.segments
+    assert got.tobytes() == ref.tobytes()

@@ -355,6 +355,23 @@ def test_switch_bounce_is_remembered_between_frames(scene_cache):
     assert third.tobytes() == ref9.tobytes()
 
 
+def test_paths_deeper_than_a_byte_counts(monkeypatch, scene_cache):
+    """The one-launch kernel carries a segment's depth through its ring beside the producer's
+    findings; depths above 255 must not wrap (week.toml's fog-filled ball keeps paths alive that
+    long).  Beyond 16 bits the call is refused."""
+    _, cam, fr = scene_cache("week")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp, depth = 64, 48, 2, 300
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=6))
+    monkeypatch.setenv("RT355_LOOP_FROM", "2")
+    img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=6))
+    assert st.trace_launches == 3 and st.max_bounce > 256  # some paths do get that deep
+    assert img.tobytes() == ref.tobytes() and st.segments == rst.segments
+    with pytest.raises(lib.RtError) as e:
+        g.render(cam(w, h), lib.render_opts(w, h, spp, 1 << 16, seed=6))
+    assert e.value.code == abi.RT_ERR_LIMIT
+
+
 def test_spin_guard_of_the_one_launch_kernel_is_reported(monkeypatch, scene_cache):
     """A wave of the kernel that follows paths to their end gives up after a fixed number of
     feed turns and drops its segments; the call must then fail instead of returning the
