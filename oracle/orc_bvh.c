@@ -428,9 +428,14 @@ uint32_t orc_tree_depth(const rt_linear_node *nodes, uint32_t n_nodes) {
  * media lies strictly inside its sphere (all eight corners, distances in double precision).
  * The first ORC_MAX_ENCLOSING such media in primitive order are left out of the tree and tested
  * once per ray before the traversal starts, in that order; a hit shortens the ray like any
- * other.  The reference has no media at all, so nothing of it is re-ordered by this. */
+ * other.  The reference has no media at all, so nothing of it is re-ordered by this; with
+ * ORC_NO_ENCLOSING=1 the tree is built over every primitive as BVH::new does
+ * (shapes/src/bvh.rs:108-151), and hits, any-hit answers and frames must come out the same. */
 static void find_enclosing(orc_scene *s, const aabb *bounds) {
     s->n_enclosing = 0;
+    /* ORC_NO_ENCLOSING: the literal build, BVH::new over all primitives (shapes/src/bvh.rs:108-151);
+     * tests compare results with and without */
+    if (getenv("ORC_NO_ENCLOSING")) return;
     aabb others = aabb_empty();
     int any = 0;
     for (uint32_t i = 0; i < s->n_prims; i++) {

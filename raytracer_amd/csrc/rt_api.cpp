@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -287,6 +288,9 @@ Aabb prim_bounds(const rt_scene &s, const rt_prim_ref &pr) {
 // nothing of it.
 std::vector<uint32_t> find_enclosing(const rt_scene &s, const std::vector<Aabb> &bounds) {
     std::vector<uint32_t> out;
+    // test hook: the literal build, BVH::new over all primitives (shapes/src/bvh.rs:108-151);
+    // hits, any-hit answers and frames must not depend on it
+    if (getenv("RT355_NO_ENCLOSING")) return out;
     auto sphere_medium = [&](const rt_prim_ref &p) {
         return (p.kind & 0xffu) == RT_MEDIUM && s.media[p.index].boundary_kind == RT_BOUNDARY_SPHERE;
     };
@@ -512,6 +516,71 @@ bool is_sampled_light(const rt_scene &s, const rt_prim_ref &pr) {
            s.textures[m.texture].kind == RT_TEX_SOLID;
 }
 
+// Record order for trees that are traversed from global memory.  Every interior step is a
+// dependent 64-byte fetch at a random place of a table far larger than the caches; in the
+// pre-order numbering only a node's first child is its neighbour.  Here records are grouped
+// into clusters of up to `size` records that form a connected piece of the tree around the
+// cluster's root: the piece grows by the fringe node with the largest box area (the one a
+// ray that reached the piece is most likely to visit next), so the few steps a ray makes
+// after entering a cluster tend to touch the same few cache lines and the same DRAM page.
+// Clusters follow one another in depth-first order of their roots, larger boxes first, and
+// start at multiples of `align` records (unused records are zero and never referenced).
+// RT355_NODE_CLUSTER = "size[,align]" overrides the shape; size 1 keeps the pre-order.
+// Returns the number of records of the table, unused ones included.
+constexpr uint32_t kNodeCluster = 1, kNodeClusterAlign = 1;
+uint32_t cluster_records(const std::vector<rt_linear_node> &nodes, std::vector<uint32_t> &record_of) {
+    uint32_t size = kNodeCluster, align = kNodeClusterAlign;
+    if (const char *e = getenv("RT355_NODE_CLUSTER")) {
+        unsigned a = 0, b = 0;
+        const int got = sscanf(e, "%u,%u", &a, &b);
+        if (got >= 1 && a >= 1 && a <= 4096) size = a;
+        align = got >= 2 && b >= 1 && b <= 4096 ? b : 1;
+    }
+    uint32_t n_pairs = 0;
+    for (const rt_linear_node &n : nodes) n_pairs += n.primitive_count == 0;
+    if (size <= 1) return n_pairs;
+    auto area = [&](uint32_t i) {
+        const rt_linear_node &n = nodes[i];
+        const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Cand {
+        float area;
+        uint32_t node;
+        bool operator<(const Cand &o) const { return area < o.area || (area == o.area && node > o.node); }
+    };
+    std::vector<uint32_t> roots; // cluster roots still to lay out (a stack: depth first)
+    std::vector<Cand> fringe;    // heap
+    uint32_t next = 0;
+    if (nodes[0].primitive_count == 0) roots.push_back(0);
+    while (!roots.empty()) {
+        const uint32_t root = roots.back();
+        roots.pop_back();
+        next = (next + align - 1) / align * align;
+        fringe.clear();
+        fringe.push_back(Cand{area(root), root});
+        uint32_t taken = 0;
+        while (taken < size && !fringe.empty()) {
+            std::pop_heap(fringe.begin(), fringe.end());
+            const uint32_t x = fringe.back().node;
+            fringe.pop_back();
+            record_of[x] = next++;
+            taken++;
+            const uint32_t kids[2] = {x + 1, nodes[x].child_offset};
+            for (uint32_t c : kids)
+                if (nodes[c].primitive_count == 0) {
+                    fringe.push_back(Cand{area(c), c});
+                    std::push_heap(fringe.begin(), fringe.end());
+                }
+        }
+        // what is left of the fringe starts clusters of its own: smallest box first onto the
+        // stack, so that the largest is laid out next
+        std::sort(fringe.begin(), fringe.end());
+        for (const Cand &c : fringe) roots.push_back(c.node);
+    }
+    return next;
+}
+
 // Lays the scene out for the kernels: one 64-byte record per interior node with
 // the boxes of both children, the primitive list in leaf order, and every typed
 // table re-packed in the order the leaves reference it so that a leaf's
@@ -524,6 +593,32 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     uint32_t n_pairs = 0;
     for (size_t i = 0; i < nodes.size(); i++)
         if (nodes[i].primitive_count == 0) record_of[i] = n_pairs++;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    // A lane stacks at most one far child per interior level, i.e. max_depth - 1 entries; the
+    // first stack_lds of them live in LDS, the rest in private memory.  If the records and at
+    // least kMinLds stack levels of a 1024-thread workgroup fit in one CU's LDS the tree is
+    // traversed from LDS (one workgroup per CU, 16-bit references); otherwise 256-thread
+    // workgroups read records from global memory, with as many stack levels in LDS as still
+    // leave room for kGlobalWaves workgroups per CU.
+    const uint32_t slots = s.tree.max_depth > 1 ? s.tree.max_depth - 1 : 1;
+    const size_t lds_cu = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlockOptin);
+    constexpr uint32_t kMinLds = 8;
+    const char *force = getenv("RT355_NODES"); // "global": override for experiments
+    bool lds_nodes = false;
+    uint32_t stack_lds = 0;
+    if (n_pairs > 0 && n_pairs < 0x8000u && s.prims.size() < 0x8000u && (size_t)n_pairs * 64 < lds_cu) {
+        const size_t room = lds_cu - (size_t)n_pairs * 64;
+        stack_lds = (uint32_t)std::min<size_t>(slots, room / (1024 * 6));
+        lds_nodes = stack_lds >= std::min(slots, kMinLds);
+    }
+    if (force && !strcmp(force, "global")) lds_nodes = false;
+    if (!lds_nodes) stack_lds = (uint32_t)std::min<size_t>(slots, (lds_cu / rt::kGlobalWaves - 512) / (256 * 8));
+    // Trees that stay in global memory: records are laid out in clusters instead (see
+    // cluster_records).  Record numbers are internal to the device tables, so the visiting
+    // order, the results and rt_scene_get_nodes do not change.
+    uint32_t n_records = n_pairs;
+    if (!lds_nodes && n_pairs > 1) n_records = cluster_records(nodes, record_of);
     // primitives the plain shader does not cover by kind
     auto rare_prim = [&](const rt_prim_ref &pr) {
         const uint32_t kind = pr.kind & 0xffu;
@@ -552,7 +647,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         memcpy(&f, &v, 4);
         return f;
     };
-    std::vector<float4> dn(4 * (size_t)n_pairs);
+    std::vector<float4> dn(4 * (size_t)n_records, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     for (size_t i = 0; i < nodes.size(); i++) {
         const rt_linear_node &n = nodes[i];
         if (n.primitive_count) continue;
@@ -767,27 +862,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     db.allocs.push_back(p);
     db.counters = static_cast<unsigned long long *>(p);
 
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    // Persistent grid.  A lane stacks at most one far child per interior level, i.e.
-    // max_depth - 1 entries; the first stack_lds of them live in LDS, the rest in private
-    // memory.  If the records and at least kMinLds stack levels of a 1024-thread workgroup
-    // fit in one CU's LDS the tree is traversed from LDS (one workgroup per CU, 16-bit
-    // references); otherwise 256-thread workgroups read records from global memory, with
-    // as many stack levels in LDS as still leave room for kGlobalWaves workgroups per CU.
-    const uint32_t slots = s.tree.max_depth > 1 ? s.tree.max_depth - 1 : 1;
-    const size_t lds_cu = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlockOptin);
-    constexpr uint32_t kMinLds = 8;
-    const char *force = getenv("RT355_NODES"); // "global": override for experiments
-    bool lds_nodes = false;
-    uint32_t stack_lds = 0;
-    if (n_pairs > 0 && n_pairs < 0x8000u && leaf.size() < 0x8000u && (size_t)n_pairs * 64 < lds_cu) {
-        const size_t room = lds_cu - (size_t)n_pairs * 64;
-        stack_lds = (uint32_t)std::min<size_t>(slots, room / (1024 * 6));
-        lds_nodes = stack_lds >= std::min(slots, kMinLds);
-    }
-    if (force && !strcmp(force, "global")) lds_nodes = false;
-    if (!lds_nodes) stack_lds = (uint32_t)std::min<size_t>(slots, (lds_cu / rt::kGlobalWaves - 512) / (256 * 8));
+    // Persistent grid (the node source and the LDS share of the stacks were chosen above).
     // test hook: fewer LDS levels, so that the private part of the stack is exercised
     if (const char *cap = getenv("RT355_STACK_LDS")) {
         const uint32_t v = (uint32_t)atoi(cap);

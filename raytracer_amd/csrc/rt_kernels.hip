@@ -85,6 +85,7 @@ struct TreeView {
     typename Shape<LDSN>::RefT *ref; // stack part in LDS: ref[level * kThreads], near[level * kThreads]
     float *near;
     uint32_t levels;     // stack levels kept in LDS
+    float *dump;         // !LDSN: 256 bytes behind the stacks where prefetches of far children land (never read)
 };
 
 // Carves the dynamic LDS; with LDSN also stages the records (call from all threads).
@@ -111,6 +112,7 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
     v.ref = reinterpret_cast<typename Shape<LDSN>::RefT *>(reinterpret_cast<float *>(base) +
                                                             (size_t)S.stack_lds * kThreads) +
             threadIdx.x;
+    v.dump = LDSN ? nullptr : reinterpret_cast<float *>(base) + 2 * (size_t)S.stack_lds * kThreads;
     return v;
 }
 
@@ -612,6 +614,19 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                         push(neg ? r0 : r1, neg ? t0 : t1);
                         cur = neg ? r1 : r0;
                         need_pop = false;
+#ifdef RT_PREFETCH_FAR
+                        // The far child's record is asked for now, into a dump area in LDS that nobody
+                        // reads: when the entry is popped, dozens of steps later, its fetch finds the
+                        // line in L2 or the Infinity Cache instead of paying an HBM miss in the lane's
+                        // dependent chain.
+                        if constexpr (!LDSN) {
+                            const uint32_t far = neg ? r0 : r1;
+                            if ((far >> 31) == 0)
+                                __builtin_amdgcn_global_load_lds(
+                                    (const __attribute__((address_space(1))) void *)(S.nodes + 4 * (size_t)far),
+                                    (__attribute__((address_space(3))) void *)tv.dump, 4, 0, RT_PREFETCH_FAR);
+                        }
+#endif
                     } else if (h0 || h1) {
                         cur = h0 ? r0 : r1;
                         need_pop = false;
@@ -2353,7 +2368,7 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(float4 *rgba, size_t n)
 // lane), preceded by the interior records for the LDS-resident shape
 size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds) {
     return lds_nodes ? (size_t)n_pairs * 64 + (size_t)stack_lds * 1024 * (sizeof(float) + sizeof(uint16_t))
-                     : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t));
+                     : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t)) + 256; // + the prefetch dump
 }
 
 template <class K>

@@ -4,9 +4,14 @@ all primitives, with the hit distance, the caller's primitive index, the geometr
 and the surface (u, v) under the conventions of include/rt355.h.
 
 Used by the CPU tests to check the oracle and by the GPU tests to check the HIP path's
-output directly (that comparison does not pass through oracle/ at all).  Media are not
-covered: their hit distance is a hash of the ray, which only a bit-level restatement
-could predict.
+output directly (that comparison does not pass through oracle/ at all).
+
+Media (a constant density inside a sphere or a box; no reference code, the scene files' Volume):
+the free-flight variate is a hash of the ray's 32-bit words and the primitive's index -- integer
+arithmetic, restated here bit for bit in numpy uint32 -- turned into a number u in (0, 1); the
+ray scatters after travelling -ln(u) / density inside the boundary, if it is still inside by
+then.  Everything after the hash is float64 here: the boundary's interval from the closed-form
+sphere roots or the slabs of the box, the logarithm, the distance along the ray.
 
 Tolerances.  Planar primitives reproduce float64 to within 1e-5 (t relative, normal and
 (u, v) absolute).  A sphere does not, for any fp32 quadratic: the discriminant b^2 - 4ac
@@ -43,6 +48,30 @@ from raytracer_amd import abi
 EPS = 2.0 ** -23  # f32::EPSILON, the reference's machine epsilon (geometry/src/number.rs:205)
 
 
+def ray_words(rays):
+    """The rays' origin and direction as the 32-bit words the medium's hash reads: (n, 6) uint32."""
+    o = np.ascontiguousarray(rays["o"], dtype=np.float32).view(np.uint32)
+    d = np.ascontiguousarray(rays["d"], dtype=np.float32).view(np.uint32)
+    return np.concatenate([o, d], axis=1)
+
+
+def medium_variate(words, prim):
+    """u in (0, 1) for each ray: multiply-xor over direction z, y, x and origin z, y of the ray
+    (constant 0x9E3779B1, starting from the primitive index), then one permuted-congruential
+    mixing round over the origin's x; the top 24 bits, centred in their cell."""
+    k = np.uint32(0x9E3779B1)
+    ox, oy, oz, dx, dy, dz = (words[:, i] for i in range(6))
+    with np.errstate(over="ignore"):
+        h = (np.uint32(prim) ^ dz) * k
+        for w in (dy, dx, oz, oy):
+            h = (h ^ w) * k
+        v = h ^ ox
+        st = v * np.uint32(747796405) + np.uint32(2891336453)
+        w = ((st >> ((st >> np.uint32(28)) + np.uint32(4))) ^ st) * np.uint32(277803737)
+        h = (w >> np.uint32(22)) ^ w
+    return (h >> np.uint32(8)).astype(np.float64) * 2.0 ** -24 + 2.0 ** -25
+
+
 def _m34(a):
     return np.asarray(a, dtype=np.float64).reshape(3, 4)
 
@@ -70,7 +99,7 @@ class Fp64Scene:
         k = frozen._keep
         self.k = k
         self.prims = k["prims"]
-        self.skipped_media = int((self.prims["kind"] & 0xFF == abi.RT_MEDIUM).sum())
+        self.n_media = int((self.prims["kind"] & 0xFF == abi.RT_MEDIUM).sum())
         self._object_coord = None  # largest object-space coordinate of the primitive just tested
 
     def closest(self, rays, prim_mask=None):
@@ -79,9 +108,11 @@ class Fp64Scene:
         D = rays["d"].astype(np.float64)
         tmax = rays["t_max"].astype(np.float64)
         time = rays["time"].astype(np.float64)
-        return self.closest_od(O, D, tmax, time)
+        return self.closest_od(O, D, tmax, time, ray_words(rays))
 
-    def closest_od(self, O, D, tmax, time):
+    def closest_od(self, O, D, tmax, time, words=None):
+        """words: the 32-bit words of the rays as the caller holds them (ray_words); a medium's
+        variate is a function of those, also when O and D are perturbed copies."""
         n = len(O)
         best = dict(t=np.full(n, np.inf), prim=np.full(n, -1, dtype=np.int64), n=np.zeros((n, 3)),
                     u=np.zeros(n), v=np.zeros(n), kappa=np.ones(n), radius=np.zeros(n),
@@ -112,14 +143,17 @@ class Fp64Scene:
                 elif kind == abi.RT_GSPHERE:
                     res = self._gsphere(O, D, k["gspheres"][idx], reverse)
                 else:
-                    continue  # media
+                    assert words is not None, "media need the rays' words (ray_words)"
+                    res = self._medium(O, D, tmax, k["media"][idx], medium_variate(words, pid))
                 t, ok, nrm, u, v = res[:5]
                 valid = ok & (t > 0) & (t <= tmax)
                 ok = valid & (t < best["t"])
                 # the runner-up: the old winner where this one wins, else this one if it is valid
                 best["t_second"] = np.where(ok, best["t"], np.where(valid, np.minimum(best["t_second"], t),
                                                                    best["t_second"]))
-                if len(res) > 5:  # a sphere: conditioning of its quadratic for this ray (see module text)
+                if len(res) > 7:  # a medium: conditioning and incidence of its boundary where the ray enters
+                    kappa, radius, cos_entry = res[5], res[6], res[7]
+                elif len(res) > 5:  # a sphere: conditioning of its quadratic for this ray (see module text)
                     dist_sq, radius = res[5], res[6]
                     cos_i = np.abs((nrm * D).sum(1)) / dlen
                     kappa = np.maximum(1.0, dist_sq / (radius * radius * np.maximum(cos_i, 1e-12)))
@@ -129,6 +163,8 @@ class Fp64Scene:
                 # (|d| cos(incidence)); in object space for a transformed primitive
                 coord = np.maximum(world_coord, self._object_coord) if self._object_coord is not None else world_coord
                 cos_any = np.maximum(np.abs((nrm * D).sum(1)) / (dlen * np.linalg.norm(nrm, axis=1)), 1e-3)
+                if len(res) > 7:
+                    cos_any = np.maximum(cos_entry, 1e-3)
                 best["t_resolution"] = np.where(ok, EPS * coord / (dlen * cos_any), best["t_resolution"])
                 self._object_coord = None
                 best["kappa"] = np.where(ok, kappa, best["kappa"])
@@ -243,6 +279,45 @@ class Fp64Scene:
             nrm = _unit(_apply_normal(w2o, nrm))
         return t, ok, nrm, u, v
 
+    def _medium(self, O, D, tmax, m, u):
+        """Scatter point of a constant medium: the ray is inside the boundary from t_in (0 if it
+        starts inside) to t_out (or its own end); it scatters -ln(u) / density along its path
+        from t_in, if that is still inside.  The record carries no surface: normal (1, 0, 0),
+        u = v = 0."""
+        n = len(O)
+        dlen = np.linalg.norm(D, axis=1)
+        if int(m["boundary_kind"]) == abi.RT_BOUNDARY_SPHERE:
+            sp = self.k["spheres"][int(m["boundary_index"])]
+            r = abs(float(sp["r"]))
+            oc = O - np.float64(sp["c"])
+            t0, t1, ok = self._sphere_t(oc, D, r)
+            entry = oc + D * t0[:, None]
+            cos_entry = np.where(t0 > 0, np.abs((entry * D).sum(1)) / (r * dlen), 1.0)
+            kappa = np.where(t0 > 0, np.maximum(1.0, (oc * oc).sum(1) / (r * r * np.maximum(cos_entry, 1e-12))), 1.0)
+            radius = r
+        else:
+            o, d, w2o = self._object_ray(O, D, int(m["xform"]))
+            bx = self.k["boxes"][int(m["boundary_index"])]
+            lo, hi = np.float64(bx["lo"]), np.float64(bx["hi"])
+            ta, tb = (lo - o) / d, (hi - o) / d
+            tn_axes, tf_axes = np.minimum(ta, tb), np.maximum(ta, tb)
+            along = d == 0
+            inside = (o >= lo) & (o <= hi)
+            tn_axes = np.where(along, -np.inf, tn_axes)
+            tf_axes = np.where(along, np.inf, tf_axes)
+            t0, t1 = tn_axes.max(1), tf_axes.min(1)
+            ok = (t0 <= t1) & ~(along & ~inside).any(1)
+            ax = tn_axes.argmax(1)
+            cos_entry = np.where(t0 > 0, np.abs(d[np.arange(n), ax]) / np.linalg.norm(d, axis=1), 1.0)
+            kappa, radius = np.ones(n), 0.0
+        t_in = np.maximum(t0, 0.0)
+        t_out = np.minimum(t1, tmax)
+        t = t_in + (-np.log(u) / float(m["density"])) / dlen
+        ok = ok & (t_in < t_out) & (t <= t_out)
+        nrm = np.zeros((n, 3))
+        nrm[:, 0] = 1.0
+        return t, ok, nrm, np.zeros(n), np.zeros(n), kappa, radius, cos_entry
+
     def _gsphere(self, O, D, g, reverse):
         o2w, w2o = _m34(g["o2w"]), _m34(g["w2o"])
         r = float(g["radius"])
@@ -296,6 +371,7 @@ def clear_rays(scene64, rays, best, rounds=4, seed=1, eps_o=1e-4, eps_d=1e-5):
     """True where small perturbations of the ray keep the same winner (not a grazing ray)."""
     O, D = rays["o"].astype(np.float64), rays["d"].astype(np.float64)
     tmax, time = rays["t_max"].astype(np.float64), rays["time"].astype(np.float64)
+    words = ray_words(rays)  # a medium's variate stays that of the ray itself under the perturbations
     rng = np.random.default_rng(seed)
     # two primitives at the same distance (coplanar faces of neighbouring boxes): which of them
     # is reported is a tie-break, not a geometric fact, and no perturbation separates them
@@ -304,7 +380,7 @@ def clear_rays(scene64, rays, best, rounds=4, seed=1, eps_o=1e-4, eps_d=1e-5):
     clear = ~((best["prim"] >= 0) & (gap <= 1e-5 * best["t"] + 16 * best["t_resolution"]))
     for _ in range(rounds):
         other = scene64.closest_od(O + rng.normal(size=O.shape) * eps_o, D + rng.normal(size=D.shape) * eps_d,
-                                   tmax, time)
+                                   tmax, time, words)
         clear &= other["prim"] == best["prim"]
         both = (other["prim"] >= 0) & (best["prim"] >= 0)
         # also away from t_max and from a change of face / clipping branch: the normal must not jump

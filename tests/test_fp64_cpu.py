@@ -63,7 +63,43 @@ def test_oracle_matches_fp64_on_clipped_transformed_spheres():
     # rays that enter through a cut-away part and hit the inside of the far wall are among them
     f64 = fp64_ref.Fp64Scene(fr)
     assert ((best["n"] * rays["d"]).sum(1)[clear & (best["prim"] >= 0)] > 0).mean() > 0.05
-    assert f64.skipped_media == 0
+    assert f64.n_media == 0
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_oracle_matches_fp64_with_media(seed):
+    """Fog in a sphere, smoke in a rotated box, thin fog around everything: the scatter points
+    against the float64 restatement (integer hash bit for bit, the rest in float64)."""
+    fr = mixed_scene(seed=seed, n_each=40).freeze()
+    o = orc.OracleScene(fr)
+    rays = random_rays(8000, (-12, -12, -12), (12, 12, 12), 60 + seed, finite_fraction=0.2, axis_fraction=0.0)
+    out, best, clear = check_against_fp64(o.intersect, fr, rays, min_clear=0.8)
+    kinds = fr._keep["prims"]["kind"] & 0xFF
+    hit_prims = best["prim"][clear & (best["prim"] >= 0)]
+    per_medium = [(hit_prims == m).sum() for m in np.nonzero(kinds == abi.RT_MEDIUM)[0]]
+    assert len(per_medium) == 3 and min(per_medium) > 20, per_medium
+
+
+def test_medium_variate_known_answers():
+    """The hash restated in numpy against values worked out by hand from its definition
+    (Python integers, no wrap-around tricks)."""
+    def by_hand(words, prim):
+        M = 0xFFFFFFFF
+        ox, oy, oz, dx, dy, dz = (int(w) for w in words)
+        h = ((prim ^ dz) * 0x9E3779B1) & M
+        for w in (dy, dx, oz, oy):
+            h = ((h ^ w) * 0x9E3779B1) & M
+        v = h ^ ox
+        s = (v * 747796405 + 2891336453) & M
+        w = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & M
+        h = (w >> 22) ^ w
+        return (h >> 8) * 2.0 ** -24 + 2.0 ** -25
+    rays = random_rays(64, (-5, -5, -5), (5, 5, 5), 9)
+    words = fp64_ref.ray_words(rays)
+    for prim in (0, 7, 123456):
+        got = fp64_ref.medium_variate(words, prim)
+        assert [by_hand(w, prim) for w in words] == list(got)
+        assert (got > 0).all() and (got < 1).all()
 
 
 def test_any_hit_agrees_with_fp64_closest_hit():

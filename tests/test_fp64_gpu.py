@@ -3,8 +3,9 @@ through the C ABI and without the oracle anywhere in the comparison: hit / miss 
 index equal on every ray that is not grazing, t within 1e-5 relative, geometric normals and
 (u, v) within the bounds stated in tests/fp64_ref.py -- on seeded scenes holding every surface
 kind, on the reference's clipped, transformed spheres, and on camera and random rays of the
-four named benchmark scenes (rays whose closest hit is a medium are left out: a medium's hit
-distance is a hash of the ray)."""
+four named benchmark scenes.  Media are part of it: the float64 intersector restates the hash
+behind a medium's free-flight distance bit for bit and everything after it in float64
+(tests/fp64_ref.py), so scatter points inside fog are checked like surface hits."""
 import numpy as np
 import pytest
 
@@ -29,6 +30,23 @@ def test_hip_matches_fp64_on_every_surface_kind(seed):
     assert ((g.does_intersect(rays) != 0) == (best["prim"] >= 0))[clear].all()
 
 
+@pytest.mark.parametrize("seed", [4, 5])
+def test_hip_matches_fp64_with_media(seed):
+    """The mixed scene with its three media: fog in a sphere, smoke in a rotated box, thin fog
+    around everything (kept out of the tree and tested by the traversal's first turn)."""
+    fr = mixed_scene(seed=seed, n_each=40).freeze()
+    g = lib.Scene(fr)
+    assert g.info().n_enclosing == 1
+    rays = random_rays(20000, (-12, -12, -12), (12, 12, 12), 80 + seed, finite_fraction=0.2, axis_fraction=0.0)
+    out, best, clear = check_against_fp64(g.intersect, fr, rays, min_clear=0.8, min_hits=3000)
+    kinds = fr._keep["prims"]["kind"] & 0xFF
+    hit_prims = best["prim"][clear & (best["prim"] >= 0)]
+    media = np.nonzero(kinds == abi.RT_MEDIUM)[0]
+    per_medium = [(hit_prims == m).sum() for m in media]
+    assert len(media) == 3 and min(per_medium) > 50, per_medium
+    assert ((g.does_intersect(rays) != 0) == (best["prim"] >= 0))[clear].all()
+
+
 @pytest.mark.parametrize("nodes", ["lds", "global"])
 def test_hip_matches_fp64_on_clipped_transformed_spheres(monkeypatch, nodes):
     if nodes == "global":
@@ -50,21 +68,22 @@ def test_hip_matches_fp64_on_the_benchmark_scenes(scene_cache, name):
     rays = np.concatenate([prim, random_rays(6000, lo, hi, 5, finite_fraction=0.1, axis_fraction=0.0)])
     hits = g.intersect(rays)
     kinds = fr._keep["prims"]["kind"] & 0xFF
-    medium_hit = (hits["prim"] != abi.RT_MISS) & (kinds[np.minimum(hits["prim"], len(kinds) - 1)] == abi.RT_MEDIUM)
-    keep = ~medium_hit
     f64 = fp64_ref.Fp64Scene(fr)
-    best = f64.closest(rays[keep])
-    clear = fp64_ref.clear_rays(f64, rays[keep], best, eps_o=1e-6 * float(np.abs(hi - lo).max()))
+    best = f64.closest(rays)
+    clear = fp64_ref.clear_rays(f64, rays, best, eps_o=1e-6 * float(np.abs(hi - lo).max()))
     assert clear.mean() > 0.8, clear.mean()
-    out = fp64_ref.compare(hits[keep], best, clear, **TOL)
+    out = fp64_ref.compare(hits, best, clear, **TOL)
     assert out["n_hits"] > 2000, out
+    if f64.n_media:  # scatter points in the fog are among the compared hits
+        in_fog = clear & (best["prim"] >= 0) & (kinds[np.maximum(best["prim"], 0)] == abi.RT_MEDIUM)
+        assert in_fog.sum() > 300, in_fog.sum()
 
 
 def test_hip_matches_fp64_from_inside_the_balls():
-    """Rays that start inside fog balls take the short cut that skips the tree.  Where the fog does
-    not scatter them their hit is the shell from inside, or -- fog without a shell, or a ray
-    that ends first -- whatever surface lies beyond: the float64 intersector, which knows nothing of
-    balls, must agree."""
+    """Rays that start inside fog balls take the short cut that skips the tree.  They scatter in
+    the fog, or hit the shell from inside, or -- fog without a shell, or a ray that ends first --
+    whatever surface lies beyond: the float64 intersector, which knows nothing of balls, must
+    agree on all three."""
     from tests.mixed import ball_scene, rays_inside
     sd, balls = ball_scene(seed=11)
     fr = sd.freeze()
@@ -73,12 +92,11 @@ def test_hip_matches_fp64_from_inside_the_balls():
     rays = rays_inside(balls, 8000, 11)
     hits = g.intersect(rays)
     kinds = fr._keep["prims"]["kind"] & 0xFF
-    medium_hit = (hits["prim"] != abi.RT_MISS) & (kinds[np.minimum(hits["prim"], len(kinds) - 1)] == abi.RT_MEDIUM)
-    keep = ~medium_hit
-    assert keep.sum() > 4000
     f64 = fp64_ref.Fp64Scene(fr)
-    best = f64.closest(rays[keep])
-    clear = fp64_ref.clear_rays(f64, rays[keep], best)
+    best = f64.closest(rays)
+    clear = fp64_ref.clear_rays(f64, rays, best)
     assert clear.mean() > 0.8, clear.mean()
-    out = fp64_ref.compare(hits[keep], best, clear, **TOL)
-    assert out["n_hits"] > 2000, out
+    out = fp64_ref.compare(hits, best, clear, **TOL)
+    assert out["n_hits"] > 6000, out
+    won = kinds[np.maximum(best["prim"], 0)][clear & (best["prim"] >= 0)]
+    assert (won == abi.RT_MEDIUM).sum() > 2000 and (won != abi.RT_MEDIUM).sum() > 2000  # scatters and ways out

@@ -118,6 +118,35 @@ def main():
         ms = timed(lambda: scene.intersect_dev(mid.data_ptr(), m, d_hits.data_ptr(), stream))
         out["bounce1_cell128_sorted"] = {"ms": round(ms, 3), "Mrays_s": round(m / ms / 1e3, 1)}
         del shuffled, ordered, coarse, mid
+    # What would it be worth if each XCD traced one part of the scene only, so that the eight L2s
+    # hold eight different parts of the tree?  Wave w of the global-memory kernels claims the ray
+    # blocks b with b % 32 == w % 32 and sits on XCD (w / 4) % 8, so blocks 4x ... 4x + 3 of every 32
+    # go to XCD x: the array is re-ordered so that those blocks hold rays of part x (vertical strips
+    # of the image, or slabs of the scene along x), against the same rays in their original order.
+    if "--xcd" in sys.argv:
+        pix = torch.arange(n, device="cuda")[hit]  # the pixel (path) each bounce ray came from
+        px = (pix // spp) % w
+
+        def interleave(part):
+            order = torch.argsort(part, stable=True)
+            counts = torch.bincount(part, minlength=8)
+            keep = int(counts.min().item()) // 256 * 256
+            starts = torch.cumsum(counts, 0) - counts
+            per = [order[int(starts[x]):int(starts[x]) + keep].view(-1, 256) for x in range(8)]
+            return torch.stack(per, dim=1).reshape(-1)
+
+        for label, part in (("strips", px * 8 // w),
+                            ("slabs", ((b_rays[:, 0] - b_rays[:, 0].min()) /
+                                       (b_rays[:, 0].max() - b_rays[:, 0].min() + 1e-9) * 8).long().clamp_(0, 7))):
+            sel = interleave(part)
+            by_part = b_rays[sel].contiguous()
+            same = b_rays[torch.sort(sel).values].contiguous()
+            k = by_part.shape[0]
+            ms_a = timed(lambda: scene.intersect_dev(by_part.data_ptr(), k, d_hits.data_ptr(), stream))
+            ms_b = timed(lambda: scene.intersect_dev(same.data_ptr(), k, d_hits.data_ptr(), stream))
+            out["bounce1_xcd_" + label] = {"rays": k, "Mrays_s": round(k / ms_a / 1e3, 1),
+                                           "same_rays_in_order_Mrays_s": round(k / ms_b / 1e3, 1)}
+            del by_part, same
     # host-pointer entry points: PCIe staging included (rays up, hits down)
     import time
     h_rays = b_rays[:1 << 22].cpu().numpy().view(abi.ray_dtype).reshape(-1)
