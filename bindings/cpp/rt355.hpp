@@ -83,6 +83,10 @@ class SceneBuilder {
         return push(RT_MEDIUM, uint32_t(media_.size() - 1), mat, 0);
     }
     void background(float r, float g, float b) { bg_ = {r, g, b}; }
+    // LightSource "distant": unit vector towards the light, radiance (sampled by RT_RENDER_DIRECT_LIGHT)
+    void distant_light(const float w[3], const float rgb[3]) {
+        distant_.push_back({{w[0], w[1], w[2]}, {rgb[0], rgb[1], rgb[2]}, {0u, 0u}});
+    }
 
     rt_scene_desc desc() const {
         rt_scene_desc d{};
@@ -109,6 +113,8 @@ class SceneBuilder {
         d.n_materials = uint32_t(materials_.size());
         d.n_textures = uint32_t(textures_.size());
         d.background[0] = bg_[0], d.background[1] = bg_[1], d.background[2] = bg_[2];
+        d.distant_lights = distant_.empty() ? nullptr : distant_.data();
+        d.n_distant_lights = uint32_t(distant_.size());
         return d;
     }
 
@@ -129,6 +135,7 @@ class SceneBuilder {
     std::vector<rt_material> materials_;
     std::vector<rt_texture> textures_;
     std::array<float, 3> bg_{0.f, 0.f, 0.f};
+    std::vector<rt_distant_light> distant_;
 };
 
 class Bvh {

@@ -45,6 +45,8 @@ pub struct rt_medium { pub boundary_kind: u32, pub boundary_index: u32, pub xfor
 pub struct rt_material { pub kind: u32, pub texture: u32, pub fuzz: f32, pub ior: f32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_texture { pub kind: u32, pub rgb: [f32; 3], pub a: u32, pub b: u32, pub scale: f32, pub _pad: u32 }
+#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct rt_distant_light { pub w: [f32; 3], pub rgb: [f32; 3], pub _pad: [u32; 2] }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct rt_image { pub rgb8: *const u8, pub w: u32, pub h: u32 }
 
@@ -70,7 +72,8 @@ pub struct rt_scene_desc {
     pub n_rects: u32, pub n_boxes: u32, pub n_gspheres: u32, pub n_xforms: u32,
     pub n_media: u32, pub n_materials: u32, pub n_textures: u32, pub n_images: u32,
     pub background: [f32; 3],
-    pub _pad: u32,
+    pub n_distant_lights: u32,
+    pub distant_lights: *const rt_distant_light,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
@@ -128,6 +131,7 @@ pub fn check_layout() -> Result<(), String> {
         size_of::<rt_image>(), size_of::<rt_scene_desc>(), size_of::<rt_build_opts>(),
         size_of::<rt_linear_node>(), size_of::<rt_scene_info>(), size_of::<rt_camera>(),
         size_of::<rt_filter>(), size_of::<rt_render_opts>(), size_of::<rt_stats>(),
+        size_of::<rt_distant_light>(),
     ];
     let mut theirs = [0u32; 64];
     let n = unsafe { rt_abi_sizes(theirs.as_mut_ptr(), theirs.len()) } as usize;

@@ -174,6 +174,19 @@ typedef struct rt_image {
     uint32_t w, h;
 } rt_image;
 
+/* A light infinitely far away that shines along one direction (test/test.pbrt:16-17,
+ * LightSource "distant"; the reference's parser stops before the world section, so there is no
+ * code for it there).  RT_RENDER_DIRECT_LIGHT samples it like the emissive rectangles: it is one
+ * more light of the uniform choice, and its shadow ray is Interaction::spawn_ray_to
+ * (shapes/src/interaction.rs:102-116) aimed at the point twice the scene's bounding radius away
+ * in direction w, as pbrt's distant light does.  Without that flag it adds nothing (no path
+ * can reach it by scattering). */
+typedef struct rt_distant_light {
+    float w[3];   /* unit vector from the scene towards the light */
+    float rgb[3]; /* radiance arriving from it                    */
+    uint32_t _pad[2];
+} rt_distant_light;
+
 /* Everything BVH::new + the shape constructors need.  The caller owns all
  * arrays; rt_scene_create copies what it keeps. */
 typedef struct rt_scene_desc {
@@ -196,7 +209,8 @@ typedef struct rt_scene_desc {
     uint32_t n_prims, n_spheres, n_moving_spheres, n_tris, n_rects, n_boxes;
     uint32_t n_gspheres, n_xforms, n_media, n_materials, n_textures, n_images;
     float background[3];
-    uint32_t _pad;
+    uint32_t n_distant_lights;
+    const rt_distant_light *distant_lights; /* NULL when n_distant_lights == 0 */
 } rt_scene_desc;
 
 /* SplitMethod, shapes/src/bvh.rs:10-22 (same order). */

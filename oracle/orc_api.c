@@ -28,6 +28,12 @@ static void *dup_mem(const void *src, size_t bytes) {
 }
 
 static int validate(const rt_scene_desc *d) {
+    if (d->n_distant_lights && !d->distant_lights) return 0;
+    for (uint32_t i = 0; i < d->n_distant_lights; i++) {
+        const float *w = d->distant_lights[i].w;
+        const float len2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        if (!(len2 > 0.99f && len2 < 1.01f)) return 0;
+    }
     if (d->n_prims && !d->prims) return 0;
     for (uint32_t i = 0; i < d->n_prims; i++) {
         const rt_prim_ref *p = &d->prims[i];
@@ -126,8 +132,16 @@ int orc_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, orc_scen
             s->is_light[i] = 1;
         }
     }
+    s->n_distant = d->n_distant_lights;
+    s->distant = dup_mem(d->distant_lights, sizeof(rt_distant_light) * (size_t)d->n_distant_lights);
     int rc = orc_build(s, opts);
     if (rc != RT_OK) { orc_scene_destroy(s); return rc; }
+    if (s->n_distant && (s->n_nodes || s->n_enclosing)) {
+        float wb[6];
+        orc_scene_world_bound(s, wb);
+        float hx = wb[3] - (wb[0] + wb[3]) * 0.5f, hy = wb[4] - (wb[1] + wb[4]) * 0.5f, hz = wb[5] - (wb[2] + wb[5]) * 0.5f;
+        s->distant_reach = 2.0f * sqrtf((hx * hx + hy * hy) + hz * hz);
+    }
     *out = s;
     return RT_OK;
 }
@@ -139,7 +153,7 @@ void orc_scene_destroy(orc_scene *s) {
     free(s->prims); free(s->spheres); free(s->msph); free(s->tri_verts); free(s->tri_uvs);
     free(s->tri_normals); free(s->rects); free(s->boxes); free(s->gsph); free(s->xforms);
     free(s->media); free(s->materials); free(s->textures); free(s->images); free(s->perlin_vec);
-    free(s->perlin_perm); free(s->nodes); free(s->order); free(s->lights); free(s->is_light);
+    free(s->perlin_perm); free(s->nodes); free(s->order); free(s->lights); free(s->is_light); free(s->distant);
     free(s);
 }
 

@@ -75,6 +75,12 @@ struct orc_scene {
      * DiffuseLight with a solid colour, in primitive order */
     uint32_t n_lights, *lights;
     uint8_t *is_light; /* per primitive: in `lights` */
+    /* distant lights (rt_distant_light) follow the rectangles in the uniform choice of a light;
+     * distant_reach: twice the radius of the sphere around the scene's box (pbrt's distant light
+     * aims its shadow ray at the point that far away in the light's direction) */
+    uint32_t n_distant;
+    rt_distant_light *distant;
+    float distant_reach;
     /* Media that enclose the scene are kept out of the tree (see orc_build): every ray meets
      * them, so they are tested once per ray, before the traversal, in this order. */
     uint32_t n_enclosing, enclosing[ORC_MAX_ENCLOSING];

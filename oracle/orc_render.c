@@ -574,7 +574,8 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
     v3 beta = v3_make(1.0f, 1.0f, 1.0f);
     v3 L = v3_make(0.0f, 0.0f, 0.0f);
     uint32_t segments = 0, shadow_rays = 0;
-    const int direct = (opts->flags & RT_RENDER_DIRECT_LIGHT) && s->n_lights;
+    const uint32_t n_all_lights = s->n_lights + s->n_distant; /* rectangles, then distant lights */
+    const int direct = (opts->flags & RT_RENDER_DIRECT_LIGHT) && n_all_lights;
     int skip_emission = 0; /* the previous vertex sampled the lights */
     for (uint32_t depth = 0; depth < opts->max_depth; depth++) {
         orc_surf h;
@@ -604,11 +605,32 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
             v3 a = texture_value(s, m->texture, h.u, h.v, h.p);
             if (direct) {
                 uint32_t li = 0;
-                if (s->n_lights > 1) {
-                    li = (uint32_t)(orc_rng_f(&rng) * (float)s->n_lights);
-                    if (li >= s->n_lights) li = s->n_lights - 1;
+                if (n_all_lights > 1) {
+                    li = (uint32_t)(orc_rng_f(&rng) * (float)n_all_lights);
+                    if (li >= n_all_lights) li = n_all_lights - 1;
                 }
-                float u1 = orc_rng_f(&rng), u2 = orc_rng_f(&rng);
+                float u1 = orc_rng_f(&rng), u2 = orc_rng_f(&rng); /* drawn for every kind of light */
+                if (li >= s->n_lights) {
+                    /* a distant light (test/test.pbrt:16-17): the shadow ray is spawn_ray_to the point
+                     * distant_reach away in the light's direction, outside the scene; what arrives is
+                     * albedo / pi * radiance * cos * n_lights */
+                    const rt_distant_light *dl = &s->distant[li - s->n_lights];
+                    v3 w = v3_make(dl->w[0], dl->w[1], dl->w[2]);
+                    v3 q = v3_add(h.p, v3_scale(w, s->distant_reach));
+                    rt_ray sr;
+                    orc_spawn_ray_to(h.p, h.perr, h.n, q, ray.time, &sr);
+                    v3 sd = v3_make(sr.d[0], sr.d[1], sr.d[2]);
+                    float d2 = v3_dot(sd, sd), cs = v3_dot(w, nf);
+                    if (cs > 0.0f && d2 > 0.0f) {
+                        shadow_rays++;
+                        if (!orc_any(s, &sr)) {
+                            float g = cs * ((float)n_all_lights * 0.318309886f);
+                            L = v3_add(L, v3_make(beta.x * a.x * dl->rgb[0] * g, beta.y * a.y * dl->rgb[1] * g,
+                                                  beta.z * a.z * dl->rgb[2] * g));
+                        }
+                    }
+                    goto sampled;
+                }
                 const rt_prim_ref *lp = &s->prims[s->lights[li]];
                 const rt_rect *lr = &s->rects[lp->index];
                 const rt_texture *lt = &s->textures[s->materials[lp->material].texture];
@@ -624,13 +646,14 @@ uint32_t orc_trace_path(const orc_scene *s, const rt_camera *cam, const rt_rende
                     if (!orc_any(s, &sr)) {
                         /* albedo / pi * emitted * (cs / |d|) (cl / |d|) / |d|^2 * area * n_lights */
                         float area = (lr->a1 - lr->a0) * (lr->b1 - lr->b0);
-                        float scale = area * (float)s->n_lights * 0.318309886f;
+                        float scale = area * (float)n_all_lights * 0.318309886f;
                         float g = (cs * cl) / (d2 * d2) * scale;
                         L = v3_add(L, v3_make(beta.x * a.x * lt->rgb[0] * g, beta.y * a.y * lt->rgb[1] * g,
                                               beta.z * a.z * lt->rgb[2] * g));
                     }
                 }
             }
+            sampled:
             skip_emission = direct;
             beta = v3_make(beta.x * a.x, beta.y * a.y, beta.z * a.z);
         } else if (m->kind == RT_MAT_METALLIC) {

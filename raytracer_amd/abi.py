@@ -47,6 +47,7 @@ medium_dtype = np.dtype([("boundary_kind", "<u4"), ("boundary_index", "<u4"), ("
 material_dtype = np.dtype([("kind", "<u4"), ("texture", "<u4"), ("fuzz", "<f4"), ("ior", "<f4")])
 texture_dtype = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("a", "<u4"), ("b", "<u4"),
                           ("scale", "<f4"), ("_pad", "<u4")])
+distant_light_dtype = np.dtype([("w", "<f4", 3), ("rgb", "<f4", 3), ("_pad", "<u4", 2)])
 linear_node_dtype = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("child_offset", "<u4"),
                               ("primitive_count", "<u2"), ("axis", "u1"), ("_pad", "u1")])
 
@@ -69,7 +70,7 @@ class rt_scene_desc(C.Structure):
         ("n_tris", C.c_uint32), ("n_rects", C.c_uint32), ("n_boxes", C.c_uint32),
         ("n_gspheres", C.c_uint32), ("n_xforms", C.c_uint32), ("n_media", C.c_uint32),
         ("n_materials", C.c_uint32), ("n_textures", C.c_uint32), ("n_images", C.c_uint32),
-        ("background", C.c_float * 3), ("_pad", C.c_uint32),
+        ("background", C.c_float * 3), ("n_distant_lights", C.c_uint32), ("distant_lights", C.c_void_p),
     ]
 
 
@@ -129,6 +130,7 @@ ABI_SIZES = [
     ("rt_scene_info", C.sizeof(rt_scene_info)), ("rt_camera", C.sizeof(rt_camera)),
     ("rt_filter", C.sizeof(rt_filter)),
     ("rt_render_opts", C.sizeof(rt_render_opts)), ("rt_stats", C.sizeof(rt_stats)),
+    ("rt_distant_light", distant_light_dtype.itemsize),
 ]
 
 # every symbol include/rt355.h declares

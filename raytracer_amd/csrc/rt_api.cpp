@@ -142,6 +142,7 @@ struct rt_scene {
     std::vector<float> perlin_vec;
     std::vector<int32_t> perlin_perm;
     float background[3] = {0, 0, 0};
+    std::vector<rt_distant_light> distant;
     // media that enclose the scene: kept out of the tree, tested once per ray before the
     // traversal (find_enclosing); caller's primitive indices in ascending order
     std::vector<uint32_t> enclosing;
@@ -186,6 +187,12 @@ const char *validate(const rt_scene_desc *d) {
     if (d->n_materials && !d->materials) return "materials is null";
     if (d->n_textures && !d->textures) return "textures is null";
     if (d->n_images && !d->images) return "images is null";
+    if (d->n_distant_lights && !d->distant_lights) return "distant_lights is null";
+    for (uint32_t i = 0; i < d->n_distant_lights; i++) {
+        const float *w = d->distant_lights[i].w;
+        const float len2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        if (!(len2 > 0.99f && len2 < 1.01f)) return "distant light direction is not a unit vector";
+    }
     if (d->n_xforms && !d->xforms) return "xforms is null";
     if (d->n_media && (!d->media || (!d->spheres && !d->boxes))) return "media or their boundaries are null";
     for (uint32_t i = 0; i < d->n_images; i++)
@@ -800,9 +807,24 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
         const rt_texture &t = s.textures[m.texture];
         lights.push_back(rt::LightDev{r.axis, r.k, r.a0, r.a1, r.b0, r.b1, 0.0f, {t.rgb[0], t.rgb[1], t.rgb[2]}, {0, 0}});
     }
+    const size_t n_rect_lights = lights.size(), n_all_lights = n_rect_lights + s.distant.size();
     for (rt::LightDev &l : lights) {
         const float area = (l.a1 - l.a0) * (l.b1 - l.b0);
-        l.scale = area * (float)lights.size() * 0.318309886f;
+        l.scale = area * (float)n_all_lights * 0.318309886f;
+    }
+    // Distant lights follow (axis 3): direction in a0, a1, b0; k = how far along it the point
+    // lies that the shadow ray is aimed at -- twice the radius of the sphere around the scene's
+    // box, so that it is outside the scene from wherever the ray starts (pbrt's distant light;
+    // the oracle forms the same number from the same box).
+    if (!s.distant.empty()) {
+        float wb[6];
+        if (rt_scene_world_bound(&s, wb) != RT_OK) return RT_ERR_INVALID;
+        const float hx = wb[3] - (wb[0] + wb[3]) * 0.5f, hy = wb[4] - (wb[1] + wb[4]) * 0.5f,
+                    hz = wb[5] - (wb[2] + wb[5]) * 0.5f;
+        const float reach = nodes.empty() && s.enclosing.empty() ? 0.0f : 2.0f * sqrtf((hx * hx + hy * hy) + hz * hz);
+        for (const rt_distant_light &dl : s.distant)
+            lights.push_back(rt::LightDev{3u, reach, dl.w[0], dl.w[1], dl.w[2], 0.0f, (float)n_all_lights * 0.318309886f,
+                                          {dl.rgb[0], dl.rgb[1], dl.rgb[2]}, {0, 0}});
     }
     if ((rc = upload(db, lights, &D.lights))) return rc;
     D.n_lights = (uint32_t)lights.size();
@@ -992,7 +1014,8 @@ int rt_abi_sizes(uint32_t *out, size_t cap) {
                               sizeof(rt_medium),     sizeof(rt_material),    sizeof(rt_texture),
                               sizeof(rt_image),      sizeof(rt_scene_desc),  sizeof(rt_build_opts),
                               sizeof(rt_linear_node), sizeof(rt_scene_info), sizeof(rt_camera),
-                              sizeof(rt_filter),     sizeof(rt_render_opts), sizeof(rt_stats)};
+                              sizeof(rt_filter),     sizeof(rt_render_opts), sizeof(rt_stats),
+                              sizeof(rt_distant_light)};
     size_t n = sizeof sizes / sizeof sizes[0];
     if (n > cap) n = cap;
     if (out) memcpy(out, sizes, n * sizeof(uint32_t));
@@ -1025,6 +1048,7 @@ int rt_scene_create(const rt_scene_desc *d, const rt_build_opts *opts, rt_scene 
             s->image_data.push_back(copy_in(d->images[i].rgb8, (size_t)d->images[i].w * d->images[i].h * 3));
         }
         memcpy(s->background, d->background, sizeof s->background);
+        s->distant = copy_in(d->distant_lights, d->n_distant_lights);
         for (const rt_gsphere &g : s->gspheres) s->gsph_derived.push_back(derive_gsphere(g));
         auto t0 = std::chrono::steady_clock::now();
         std::vector<Aabb> bounds(s->prims.size());

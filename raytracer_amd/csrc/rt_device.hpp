@@ -54,7 +54,9 @@ struct Medium { // 16 B
 };
 
 // A light of RT_RENDER_DIRECT_LIGHT: a rectangle without instance transform whose material is
-// a DiffuseLight with a solid colour.  scale = area * n_lights / pi (fp32, in that order).
+// a DiffuseLight with a solid colour, scale = area * n_lights / pi (fp32, in that order); or
+// (axis 3) a distant light: unit direction towards it in a0, a1, b0, radiance in rgb, k = the
+// distance along that direction of the point its shadow ray is aimed at, scale = n_lights / pi.
 struct LightDev { // 48 B
     uint32_t axis;
     float k, a0, a1, b0, b1;

@@ -1478,14 +1478,19 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
         }
         const float u1 = rng_f(rng), u2 = rng_f(rng);
         const LightDev lt = S.lights[li];
+        const bool distant = lt.axis == 3u; // the light's direction is the same from everywhere
+        const v3 w = mk(lt.a0, lt.a1, lt.b0);
         const float qa = lt.a0 + u1 * (lt.a1 - lt.a0), qb = lt.b0 + u2 * (lt.b1 - lt.b0);
-        const v3 q = lt.axis == 0 ? mk(lt.k, qa, qb) : (lt.axis == 1 ? mk(qa, lt.k, qb) : mk(qa, qb, lt.k));
+        const v3 q = distant ? h.p + w * lt.k
+                             : (lt.axis == 0 ? mk(lt.k, qa, qb) : (lt.axis == 1 ? mk(qa, lt.k, qb) : mk(qa, qb, lt.k)));
         // Interaction::spawn_ray_to, shapes/src/interaction.rs:102-116
         const v3 so = offset_origin(h.p, h.perr, h.n, q - h.p);
         const v3 sd = q - so;
-        const float d2 = dot(sd, sd), cs = dot(sd, nf), cl = fabsf(comp(sd, (int)lt.axis));
+        const float d2 = dot(sd, sd), cs = distant ? dot(w, nf) : dot(sd, nf);
+        const float cl = distant ? 1.0f : fabsf(comp(sd, (int)(lt.axis % 3u)));
         if (cs > 0.0f && cl > 0.0f && d2 > 0.0f) {
-            const float g = (cs * cl) / (d2 * d2) * lt.scale;
+            // rectangle: cos cos / distance^2 x area x n_lights / pi; distant light: cos x n_lights / pi
+            const float g = distant ? cs * lt.scale : (cs * cl) / (d2 * d2) * lt.scale;
             sh->want = true;
             sh->o = so;
             sh->d = sd;

@@ -263,10 +263,38 @@ def _params(toks, at):
     return out, at
 
 
+def blackbody_rgb(kelvin, scale=1.0):
+    """RGB of pbrt's "blackbody L" [T scale]: Planck's law sampled every nanometre over 360-830 nm,
+    normalised by its value at the Wien peak (which lies in the infrared for 3000 K), weighted
+    with the CIE 1931 matching functions, Y normalised by the integral of y-bar, then XYZ -> linear
+    sRGB primaries.  The matching functions are the multi-lobe Gaussian fit of Wyman, Sloan and
+    Shirley (2013), not the reference's tables (data/src/lib.rs), so the last digits differ from
+    a table-driven conversion by about a per cent."""
+    lam = np.arange(360.0, 831.0)
+
+    def planck(nm):
+        m = nm * 1e-9
+        h, c, kb = 6.62606957e-34, 299792458.0, 1.3806488e-23
+        return (2.0 * h * c * c) / (m ** 5 * (np.exp((h * c) / (m * kb * kelvin)) - 1.0))
+
+    v = planck(lam) / planck(2.8977721e-3 / kelvin * 1e9)
+
+    def lobe(mu, s1, s2):
+        return np.exp(-0.5 * ((lam - mu) / np.where(lam < mu, s1, s2)) ** 2)
+
+    xb = 1.056 * lobe(599.8, 37.9, 31.0) + 0.362 * lobe(442.0, 16.0, 26.7) - 0.065 * lobe(501.1, 20.4, 26.2)
+    yb = 0.821 * lobe(568.8, 46.9, 40.5) + 0.286 * lobe(530.9, 16.3, 31.1)
+    zb = 1.217 * lobe(437.0, 11.8, 36.0) + 0.681 * lobe(459.0, 26.0, 13.8)
+    x, y, z = ((v * b).sum() / yb.sum() for b in (xb, yb, zb))
+    rgb = (3.240479 * x - 1.537150 * y - 0.498535 * z, -0.969256 * x + 1.875991 * y + 0.041556 * z,
+           0.055648 * x - 0.204043 * y + 1.057311 * z)
+    return tuple(float(np.float32(max(0.0, c) * scale)) for c in rgb)
+
+
 def load_pbrt(text):
     """The subset of pbrt-v3 that test/test.pbrt needs -> (SceneData, camera_factory, settings).
-    LightSource "infinite" becomes the background radiance; "distant" lights are skipped
-    (the path tracer has no light sampling)."""
+    LightSource "infinite" becomes the background radiance; "distant" becomes a distant light
+    (SceneData.add_distant_light) that frames rendered with RT_RENDER_DIRECT_LIGHT sample."""
     toks = _tokens(text)
     s = SceneData()
     ctm = identity()
@@ -355,6 +383,16 @@ def load_pbrt(text):
             elif d == "LightSource":
                 if kind == "infinite":
                     s.background = tuple(float(v) for v in p.get("L", ("rgb", [1.0, 1.0, 1.0]))[1])
+                elif kind == "distant":
+                    # the light shines from `from` towards `to`, both in the current transform
+                    src = np.asarray(p.get("from", ("point", [0.0, 0.0, 0.0]))[1], dtype=np.float64)
+                    dst = np.asarray(p.get("to", ("point", [0.0, 0.0, 1.0]))[1], dtype=np.float64)
+                    towards = ctm[:3, :3] @ (src - dst)
+                    typ, val = p.get("L", ("rgb", [1.0, 1.0, 1.0]))
+                    rgb = blackbody_rgb(float(val[0]), float(val[1])) if typ == "blackbody" else tuple(float(v) for v in val)
+                    sc = p.get("scale", ("rgb", [1.0, 1.0, 1.0]))[1]
+                    sc = [float(v) for v in sc] * (3 if len(sc) == 1 else 1)
+                    s.add_distant_light(towards, tuple(float(np.float32(a * b)) for a, b in zip(rgb, sc)))
                 else:
                     skipped.append("LightSource " + kind)
             elif d == "Material":

@@ -253,6 +253,16 @@ class SceneData:
             self.media.append((abi.RT_BOUNDARY_BOX, self._box(box[0], box[1]), xform, density))
         return self._prim(abi.RT_MEDIUM, len(self.media) - 1, material)
 
+    def add_distant_light(self, towards, rgb):
+        """A light infinitely far away in direction `towards` (from the scene; any length) with
+        radiance rgb: LightSource "distant" of test/test.pbrt.  Sampled by RT_RENDER_DIRECT_LIGHT."""
+        w = np.asarray(towards, dtype=np.float64)
+        w = w / np.linalg.norm(w)
+        if not hasattr(self, "distant"):
+            self.distant = []
+        self.distant.append((tuple(float(x) for x in w.astype(F32)), tuple(float(x) for x in rgb), (0, 0)))
+        return len(self.distant) - 1
+
     # -- freeze --
     def n_prims(self):
         return sum(p[3] if isinstance(p[0], str) else 1 for p in self.prims)
@@ -339,4 +349,8 @@ class SceneData:
         (d.n_gspheres, d.n_xforms, d.n_media, d.n_materials, d.n_textures, d.n_images) = (
             len(gsph), len(xforms), len(media), len(mats), len(texs), len(self.images))
         d.background[:] = self.background
+        lights = getattr(self, "distant", [])
+        if lights:
+            dl = keep["distant_lights"] = np.array(lights, dtype=abi.distant_light_dtype)
+            d.distant_lights, d.n_distant_lights = dl.ctypes.data, len(dl)
         return FrozenScene(d, keep)

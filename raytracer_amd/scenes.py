@@ -171,9 +171,12 @@ def next_week(boxes_per_side=20, cube_count=1000):
 
 def pbrt_test():
     """test/test.pbrt: unit glass sphere at the origin and a 40 x 40 checkered
-    quad (two triangles, st coordinates) at z = -1 under a uniform sky.  The
-    distant light of the file is not modelled."""
+    quad (two triangles, st coordinates) at z = -1 under a uniform sky and the file's distant
+    light (a 3000 K black body scaled by 1.5, shining from (-30, 40, 100) towards pbrt's default
+    target (0, 0, 1)), which frames rendered with RT_RENDER_DIRECT_LIGHT sample."""
+    from .frontends import blackbody_rgb
     s = SceneData(background=(0.4, 0.45, 0.5))
+    s.add_distant_light((-30.0, 40.0, 99.0), blackbody_rgb(3000.0, 1.5))
     s.add_gsphere(identity(), 1.0, material=s.dielectric(1.5))
     # pbrt's checkerboard: cells with even floor(u) + floor(v) take tex1 (0.1), odd ones tex2 (0.8)
     tex1, tex2 = s.solid((0.1, 0.1, 0.1)), s.solid((0.8, 0.8, 0.8))

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from raytracer_amd import scenes  # noqa: E402
+from raytracer_amd import abi, scenes  # noqa: E402
 from tests import orc  # noqa: E402
 from tests.conftest import random_rays  # noqa: E402
 from tests.mixed import mixed_scene  # noqa: E402
@@ -45,6 +45,11 @@ def main():
             img, st = o.render(cam(64, 48), orc.render_opts(64, 48, 2, 20, seed=11))
             out["image"] = img
             out["segments"] = np.uint64(st.segments)
+            # the same frame with the lights sampled (emissive rectangles; test.pbrt's distant light)
+            img, st = o.render(cam(64, 48), orc.render_opts(64, 48, 2, 20, seed=11, flags=abi.RT_RENDER_DIRECT_LIGHT))
+            out["image_direct"] = img
+            out["segments_direct"] = np.uint64(st.segments)
+            out["occlusion_direct"] = np.uint64(st.occlusion_rays)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, len(rays), "rays,", int((hits["prim"] != 0xFFFFFFFF).sum()), "hits")
 

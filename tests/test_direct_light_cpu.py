@@ -127,3 +127,74 @@ def test_emitters_outside_the_light_list_keep_their_emission():
     share = (lit - dark)[floor][:, :3].mean(0)
     want = alone[floor][:, :3].mean(0)
     assert want.min() > 0.003 and np.abs(share / want - 1.0).max() < 0.05, (share, want)
+
+
+def floor_under_sun(albedo=(0.6, 0.5, 0.4), sun=(2.0, 1.5, 1.0), towards=(1.0, 2.0, -0.5), ball=True, lamp=False,
+                    lamp_emit=5.0):
+    """A Lambertian floor (y = 0) under a distant light, black sky; optionally a ball that casts
+    a shadow and a rectangular lamp (then the flag chooses between two lights)."""
+    s = SceneData()
+    s.add_rect(1, 0.0, -50.0, 50.0, -50.0, 50.0, s.lambertian(albedo))
+    if ball:
+        s.add_sphere((0.0, 1.0, 0.0), 0.5, s.lambertian((0.5, 0.5, 0.5)))
+    if lamp:
+        s.add_rect(1, 3.0, -1.0, 1.0, -0.5, 0.5, s.diffuse_light((lamp_emit, lamp_emit, lamp_emit)))
+    s.add_distant_light(towards, sun)
+    cam = perspective_camera(32, 32, 30.0, look_at((0.0, 4.0, -8.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)))
+    return s, cam
+
+
+def test_distant_light_closed_form():
+    """LightSource "distant" (test/test.pbrt:16-17) under RT_RENDER_DIRECT_LIGHT, paths of one
+    segment, black sky: a floor pixel in the sun holds albedo / pi * radiance * cos(angle between
+    the floor's normal and the light) for every sample, exactly the same number; a pixel in the
+    ball's shadow holds nothing.  Where the shadow falls follows from the geometry: the floor point
+    p is shaded when the line p + s w passes the ball's centre closer than its radius."""
+    albedo, sun, towards = (0.6, 0.5, 0.4), (2.0, 1.5, 1.0), np.array([1.0, 2.0, -0.5])
+    s, cam = floor_under_sun(albedo, sun, towards)
+    o = orc.OracleScene(s.freeze())
+    w = h = 32
+    opts = dict(sampler=abi.RT_SAMPLER_STRATIFIED, sampler_arg=1 | abi.RT_STRATIFIED_NO_JITTER)
+    img, st = o.render(cam, orc.render_opts(w, h, 1, 1, seed=1, flags=abi.RT_RENDER_DIRECT_LIGHT, **opts))
+    rays = orc.generate_rays(cam, orc.render_opts(w, h, 1, **opts), 0, w * h)
+    hits = o.intersect(rays)
+    floor = hits["prim"] == 0
+    assert floor.sum() > 700 and st.occlusion_rays >= floor.sum()
+    P = rays["o"].astype(np.float64) + hits["t"][:, None].astype(np.float64) * rays["d"].astype(np.float64)
+    wdir = towards / np.linalg.norm(towards)
+    oc = P - np.array([0.0, 1.0, 0.0])
+    along = oc @ wdir
+    dist = np.sqrt(np.maximum((oc * oc).sum(1) - along ** 2, 0.0))
+    in_shadow = floor & (dist < 0.5 - 1e-3) & (along < 0)
+    in_sun = floor & (dist > 0.5 + 1e-3)
+    assert in_shadow.sum() > 10 and in_sun.sum() > 600
+    got = img.reshape(-1, 4)[:, :3]
+    want = np.array(albedo) / np.pi * np.array(sun) * wdir[1]
+    assert np.abs(got[in_sun] / want - 1.0).max() < 1e-5
+    assert (got[in_shadow] == 0).all()
+    # without the flag the light adds nothing: no path reaches it by scattering
+    plain, pst = o.render(cam, orc.render_opts(w, h, 1, 4, seed=1, **opts))
+    assert pst.occlusion_rays == 0 and (plain[..., :3] == 0).all()
+    # the far side of a surface gets nothing: a light below the floor
+    s2, cam2 = floor_under_sun(albedo, sun, (1.0, -2.0, -0.5), ball=False)
+    below, bst = orc.OracleScene(s2.freeze()).render(cam2, orc.render_opts(w, h, 1, 1, seed=1, flags=abi.RT_RENDER_DIRECT_LIGHT, **opts))
+    assert bst.occlusion_rays == 0 and (below[..., :3] == 0).all()
+
+
+def test_distant_light_shares_the_choice_with_the_lamps():
+    """One light is chosen uniformly among rectangles and distant lights and weighted by their
+    number: over many samples the floor receives lamp + sun, each as when the other is black
+    (the lamp stays in place when it is black: it also casts a shadow)."""
+    w = h = 32
+    flag = abi.RT_RENDER_DIRECT_LIGHT
+
+    def render(**kw):
+        s, cam = floor_under_sun(ball=False, **kw)
+        return orc.OracleScene(s.freeze()).render(cam, orc.render_opts(w, h, 256, 1, seed=2, flags=flag))[0][..., :3]
+
+    both = render(lamp=True)
+    sun_only = render(lamp=True, lamp_emit=0.0)
+    lamp_only = render(lamp=True, sun=(0.0, 0.0, 0.0))
+    m = (lamp_only.sum(-1) > 0.05) & (lamp_only.sum(-1) < 2.0)  # floor pixels the lamp lights, not the lamp itself
+    assert m.sum() > 50
+    assert abs(both[m].sum() / (sun_only[m].sum() + lamp_only[m].sum()) - 1.0) < 0.02

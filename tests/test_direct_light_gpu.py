@@ -119,3 +119,45 @@ def test_emissive_sphere_beside_a_sampled_light():
     got, gst = g.render(cam, lib.render_opts(w, h, 16, 4, seed=5, flags=FLAG))
     assert gst.occlusion_rays == rst.occlusion_rays > 0 and gst.segments == rst.segments
     assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("nodes", ["lds", "global"])
+def test_distant_light_bit_exact(monkeypatch, nodes):
+    """LightSource "distant": alone (closed-form floor, see the CPU test), sharing the choice with
+    a lamp, and on test.pbrt's scene with several sample batches and shards."""
+    from tests.test_direct_light_cpu import floor_under_sun
+    if nodes == "global":
+        monkeypatch.setenv("RT355_NODES", "global")
+    w = h = 32
+    for kw in (dict(), dict(lamp=True), dict(ball=False, towards=(1.0, -2.0, -0.5))):
+        s, cam = floor_under_sun(**kw)
+        fr = s.freeze()
+        g, o = lib.Scene(fr), orc.OracleScene(fr)
+        for depth in (1, 6):
+            ref, rst = o.render(cam, orc.render_opts(w, h, 4, depth, seed=3, flags=FLAG))
+            got, gst = g.render(cam, lib.render_opts(w, h, 4, depth, seed=3, flags=FLAG))
+            assert got.tobytes() == ref.tobytes(), (kw, depth)
+            assert gst.occlusion_rays == rst.occlusion_rays and gst.segments == rst.segments
+
+
+def test_distant_light_on_the_pbrt_scene(scene_cache):
+    _, cam, fr = scene_cache("pbrt")
+    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    w, h, spp, depth = 120, 80, 4, 20
+    c = cam(w, h)
+    kw = dict(sampler=abi.RT_SAMPLER_HALTON)
+    ref, rst = o.render(c, orc.render_opts(w, h, spp, depth, seed=2, flags=FLAG | abi.RT_RENDER_COUNTERS, **kw))
+    got, gst = g.render(c, lib.render_opts(w, h, spp, depth, seed=2, flags=FLAG | abi.RT_RENDER_COUNTERS, **kw))
+    assert rst.occlusion_rays > w * h
+    assert gst.occlusion_rays == rst.occlusion_rays and gst.segments == rst.segments
+    assert gst.nodes_visited == rst.nodes_visited and list(gst.prims_tested) == list(rst.prims_tested)
+    assert got.tobytes() == ref.tobytes()
+    got2, st2 = g.render(c, lib.render_opts(w, h, spp, depth, seed=2, flags=FLAG, max_paths=w * h, **kw))
+    assert st2.batches > 1 and got2.tobytes() == ref.tobytes()
+    total = np.zeros_like(got)
+    for k in range(3):
+        part, _ = g.render(c, lib.render_opts(w, h, spp, depth, seed=2, flags=FLAG, shard=(k, 3), **kw))
+        total += part
+    assert total.tobytes() == ref.tobytes()
+    plain, pst = g.render(c, lib.render_opts(w, h, spp, depth, seed=2, **kw))
+    assert pst.occlusion_rays == 0 and plain.tobytes() != got.tobytes()

@@ -52,7 +52,8 @@ def canonical(sd):
             geom = k[tables[kind]][int(p["index"])].tobytes()
         xf = k["xforms"][int(p["xform"]) - 1].tobytes() if int(p["xform"]) else b""
         out.append((int(p["kind"]), geom, xf, mat(int(p["material"]))))
-    return out, tuple(fr.desc.background)
+    lights = k["distant_lights"].tobytes() if "distant_lights" in k else b""
+    return out, (tuple(fr.desc.background), lights)
 
 
 @pytest.mark.parametrize("name", ["week", "cornell", "random", "globe", "perlin", "scene", "camera"])
@@ -90,7 +91,25 @@ def test_settings_follow_the_files():
     assert (st["width"], st["height"], st["spp"], st["max_depth"]) == (800, 800, 10000, 50)
     _, _, st = frontends.load(os.path.join(HERE, "test.pbrt"))
     assert (st["width"], st["height"], st["spp"], st["sampler"]) == (400, 400, 128, "halton")
-    assert "LightSource distant" in st["skipped"]
+    assert st["skipped"] == []  # every directive of the file is modelled
+    sd, _, _ = frontends.load(os.path.join(HERE, "test.pbrt"))
+    (w, rgb, _), = sd.distant  # LightSource "distant" "point from" [-30 40 100] "blackbody L" [3000 1.5]
+    towards = np.array([-30.0, 40.0, 100.0]) - np.array([0.0, 0.0, 1.0])  # "to" defaults to (0, 0, 1) in pbrt
+    assert np.allclose(w, towards / np.linalg.norm(towards), atol=1e-7)
+    assert rgb[0] > rgb[1] > rgb[2] > 0 and 0.9 < rgb[0] < 1.3  # a warm white, 1.5 x a 3000 K black body
+
+
+def test_blackbody_colour():
+    """The conversion behind "blackbody L": chromaticity of Planck's law against published CIE 1931
+    values (x, y) = (0.4369, 0.4041) at 3000 K and (0.3135, 0.3237) at 6500 K, and the scale."""
+    m = np.linalg.inv(np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556],
+                                [0.055648, -0.204043, 1.057311]]))
+    for kelvin, xy in ((3000.0, (0.4369, 0.4041)), (6500.0, (0.3135, 0.3237))):
+        X, Y, Z = m @ np.array(frontends.blackbody_rgb(kelvin), dtype=np.float64)
+        # negative primaries are clipped at 3000 K, which moves the point a little
+        assert abs(X / (X + Y + Z) - xy[0]) < 0.012 and abs(Y / (X + Y + Z) - xy[1]) < 0.012, (kelvin, X, Y, Z)
+    a, b = frontends.blackbody_rgb(3000.0, 1.0), frontends.blackbody_rgb(3000.0, 1.5)
+    assert np.allclose(np.array(a) * 1.5, b, rtol=1e-6)
 
 
 def test_errors_name_the_problem():

@@ -35,6 +35,9 @@ def test_oracle_reproduces_golden(name):
     if cam is not None:
         img, st = o.render(cam(64, 48), orc.render_opts(64, 48, 2, 20, seed=11))
         assert img.tobytes() == z["image"].tobytes() and st.segments == z["segments"]
+        img, st = o.render(cam(64, 48), orc.render_opts(64, 48, 2, 20, seed=11, flags=abi.RT_RENDER_DIRECT_LIGHT))
+        assert img.tobytes() == z["image_direct"].tobytes()
+        assert st.segments == z["segments_direct"] and st.occlusion_rays == z["occlusion_direct"]
 
 
 @pytest.mark.gpu
@@ -48,3 +51,6 @@ def test_hip_reproduces_golden(name):
     if cam is not None:
         img, st = g.render(cam(64, 48), lib.render_opts(64, 48, 2, 20, seed=11))
         assert img.tobytes() == z["image"].tobytes() and st.segments == z["segments"]
+        img, st = g.render(cam(64, 48), lib.render_opts(64, 48, 2, 20, seed=11, flags=abi.RT_RENDER_DIRECT_LIGHT))
+        assert img.tobytes() == z["image_direct"].tobytes()
+        assert st.segments == z["segments_direct"] and st.occlusion_rays == z["occlusion_direct"]
