@@ -15,18 +15,26 @@ frame: total work is fixed, so scaling is "strong".
 
 Extra objects on the JSON line:
   roofline     -- the bounce kernels (k_bounce: one launch per bounce while the
-                  queue is large; k_bounce_loop: one launch for all later bounces):
-                  algorithmic bytes of all ray segments of a frame (traversal
-                  counters of an untimed counting frame; identical to the oracle's)
-                  over the summed duration of the frame's bounce launches, measured
-                  with HIP events recorded on the launch stream inside the timed
-                  steps.  On this scene the tree is read from LDS, so those bytes never
-                  reach HBM and the kernel's real limit is vector-instruction issue:
-                  `bound` says so, and `traffic` (HBM bytes per launch) and `valu`
-                  (instructions per segment, issue rate against the chip's, active
-                  lanes) carry the hardware counters of a separate rocprofv3 run --
-                  only when that run was made with the kernel sources of this tree
-                  (a hash of them is stored with the counters), null otherwise.
+                  queue is large; k_bounce_loop: one launch for all later bounces).
+                  `bound` names the resource that limits them and `achieved / peak /
+                  frac` are of THAT resource:
+                    week scene (tree in LDS): "valu" -- wave-level vector instructions
+                      per second (count from a rocprofv3 --pmc run of these very kernel
+                      sources, time from HIP events recorded on the launch stream inside
+                      the timed steps) against the issue rate tools/valu_peak.hip
+                      measured on this chip; `frac_vs_guide_peak` is the same against
+                      2 cycles per wave64 instruction;
+                    --config C5 (tree in global memory): "hbm" -- 64-byte requests that
+                      leave L2 per second against the rate tools/gather_peak.hip measured
+                      for dependent random 64-byte record reads from a table of the
+                      tree's size.
+                  `algorithmic` is the reading the metric's definition asks for:
+                  algorithmic bytes of all ray segments of a frame (traversal counters
+                  of an untimed counting frame; identical to the oracle's) over the
+                  summed duration of the frame's bounce launches, against the 8 TB/s
+                  HBM peak.  `traffic` is HBM bytes per launch from the counters.
+                  Counter-based fields are null when the counter file was not measured
+                  on the kernel sources of this tree (a hash is stored with it).
   cpu_baseline -- the CPU oracle (a port of the reference algorithm, not the
                   product) built -O3 -march=native -ffp-contract=off on the machine
                   and timed on its host cores on a bounded sample, before the GPU
@@ -43,11 +51,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 50
+# name of the scene builder, frame, label of the workload
+CONFIGS = {
+    "C3": dict(scene="week", width=1920, height=1080, spp=64, depth=50, label="week.toml Next-Week scene"),
+    "C5": dict(scene="synthetic", width=3840, height=2160, spp=128, depth=8,
+               label="synthetic scene (1 M-triangle terrain + 10 M spheres)"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # algorithmic bytes: ray read + hit/next-ray write + 32 B per node visited + record per primitive tested
 RAY_BYTES, OUT_BYTES, NODE_BYTES = 32, 32, 32
 PRIM_BYTES = [16, 32, 36, 24, 24, 124, 32, 0]  # sphere, moving, triangle, rect, box, gsphere, medium
+# Vector-instruction issue: 256 CUs x 4 SIMDs; the guide's 2 cycles per wave64 instruction at 2.4 GHz
+GUIDE_ISSUE_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
+# Dependent random reads of 64-byte records from a table of the C5 tree's size (0.7 GB of records beside
+# 0.5 GB of other tables), 6 waves per SIMD: tools/gather_peak.hip, profiles/r03_gather_peak.jsonl
+GATHER_PEAK_GREC_S = 57.0
 
 
 def algorithmic_bytes(stats):
@@ -96,22 +114,24 @@ def native_oracle():
         return "gcc -O3 -ffp-contract=off (portable build; native build failed)"
 
 
-def cpu_baseline(frozen, cam, threads, target_s=15.0):
+def cpu_baseline(frozen, cam, cfg, threads, target_s=15.0):
     """Oracle (port of the reference path) on the host cores, bounded sample:
-    the same 1920x1080 frame at fewer samples per pixel."""
+    the same frame at fewer samples per pixel."""
     flags = native_oracle()
     from tests import orc
+    w, h, depth = cfg["width"], cfg["height"], cfg["depth"]
     o = orc.OracleScene(frozen)
     t0 = time.time()
-    _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, 1, DEPTH, seed=0), threads=threads)
+    _, st = o.render(cam, orc.render_opts(w, h, 1, depth, seed=0), threads=threads)
     t1 = time.time() - t0
-    spp = max(1, min(SPP, int(target_s / max(t1, 1e-3))))
-    t0 = time.time()
-    _, st = o.render(cam, orc.render_opts(WIDTH, HEIGHT, spp, DEPTH, seed=0), threads=threads)
-    dt = time.time() - t0
-    return {"value": round(st.segments / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+    spp = max(1, min(cfg["spp"], int(target_s / max(t1, 1e-3))))
+    if spp > 1:
+        t0 = time.time()
+        _, st = o.render(cam, orc.render_opts(w, h, spp, depth, seed=0), threads=threads)
+        t1 = time.time() - t0
+    return {"value": round(st.segments / t1 / 1e6, 3), "unit": "Mrays/s", "cores": threads,
             "kind": "port", "build": flags,
-            "sample": "week scene %dx%d, %d of %d spp, depth %d (%.1f s)" % (WIDTH, HEIGHT, spp, SPP, DEPTH, dt)}
+            "sample": "%s %dx%d, %d of %d spp, depth %d (%.1f s)" % (cfg["scene"], w, h, spp, cfg["spp"], depth, t1)}
 
 
 def main():
@@ -119,7 +139,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="debug only; the headline is 64")
+    ap.add_argument("--spp", type=int, default=0, help="debug only; the headline is 64 (C5: 128)")
+    ap.add_argument("--config", default="C3", choices=["C3", "C5"],
+                    help="C3: the headline (week.toml 1080p x 64 spp).  C5: the large synthetic scene at "
+                         "4K x 128 spp, depth 8 (set-up takes a minute; no CPU leg unless --cpu-threads is given)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verbose", action="store_true")
@@ -130,6 +153,9 @@ def main():
                     help="rehearsal only: a world of one still joins the process group and runs the frame's "
                          "reduce, the barriers and the all-reduces through the backend (RCCL with one rank)")
     args = ap.parse_args()
+    if os.environ.get("RT355_BENCH_WATCHDOG"):  # seconds after which every thread's stack is printed and the run ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RT355_BENCH_WATCHDOG"]), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -153,24 +179,28 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    sd, camf = scenes.next_week()
+    cfg = CONFIGS[args.config]
+    WIDTH, HEIGHT, DEPTH = cfg["width"], cfg["height"], cfg["depth"]
+    if not args.spp:
+        args.spp = cfg["spp"]
+    sd, camf = scenes.BUILDERS[cfg["scene"]]()
     frozen = sd.freeze()
     cam = camf(WIDTH, HEIGHT)
     # CPU leg first (rank 0 of a single-GPU run only): the GPU phase then runs in one piece
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and (args.config == "C3" or args.cpu_threads):
         threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
-        cpu = cpu_baseline(frozen, cam, threads)
+        cpu = cpu_baseline(frozen, cam, cfg, threads)
     scene = lib.Scene(frozen, 4, abi.RT_SPLIT_SAH, device=local_rank)
     scene.upload()
     info = scene.info()
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def frame(flags=0):
+    def frame(flags=0, want_stats=True):
         def shard(index, count, buf):
             opts = lib.render_opts(WIDTH, HEIGHT, args.spp, DEPTH, seed=0, shard=(index, count), flags=flags)
-            return scene.render_dev(cam, opts, buf.data_ptr(), stream)
+            return scene.render_dev(cam, opts, buf.data_ptr(), stream, want_stats=want_stats)
 
         return render_frame(shard, fb, rank, world, dist, single_rank_collective=args.single_rank_collective)
 
@@ -187,17 +217,34 @@ def main():
     for _ in range(args.warmup):
         frame()
     fence()
+    # One rank: every timed frame carries HIP events around its bounce launches (what the roofline's
+    # kernel time is made of) and is waited for.  Ranks joined by RCCL: a rank enqueues frame and
+    # reduce on its stream without waiting in between -- its segment count is that of the counting
+    # frame, the scene and the seed being the same -- and one more frame after the timed region
+    # takes the kernel times.  (The gloo rehearsal, where ranks share one GPU, waits for every frame:
+    # gloo stages through the host anyway, and two processes that both keep a deep queue of
+    # persistent kernels on one device were seen to stall each other.)
+    wait_frames = not (use_dist and args.backend == "nccl")
     t0 = time.perf_counter()
     segments = 0
     trace_ms = 0.0
     launches = 0
     for _ in range(args.steps):
-        st = frame(abi.RT_RENDER_TIMING)
-        segments += st.segments
-        trace_ms += st.trace_ms
-        launches += st.trace_launches
+        if wait_frames:
+            st = frame(abi.RT_RENDER_TIMING)
+            trace_ms += st.trace_ms
+            launches += st.trace_launches
+            segments += st.segments
+        else:
+            frame(want_stats=False)
+            segments += counted.segments
     fence()
     elapsed = time.perf_counter() - t0
+    timed_frames = args.steps
+    if not wait_frames:
+        st = frame(abi.RT_RENDER_TIMING)
+        trace_ms, launches, timed_frames = st.trace_ms, st.trace_launches, 1
+        fence()
 
     tot = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device="cuda")
     if use_dist:
@@ -212,53 +259,75 @@ def main():
         print("frame sha256", hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest(), file=sys.stderr)
     if rank == 0:
         alg_bytes = algorithmic_bytes(counted)  # per frame, this rank's shard
+        frame_trace_s = trace_ms / max(timed_frames, 1) * 1e-3  # bounce launches of one frame
         per_launch_ms = trace_ms / max(launches, 1)
-        launches_per_frame = launches / max(args.steps, 1)
-        achieved = alg_bytes / (trace_ms / args.steps * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        launches_per_frame = launches / max(timed_frames, 1)
+        alg_gbs = alg_bytes / frame_trace_s / 1e9 if trace_ms > 0 else 0.0
+        lds_tree = args.config == "C3"
+        roofline = {
+            "kernel": "k_bounce + k_bounce_loop",
+            "bound": "valu" if lds_tree else "hbm",
+            "achieved": None, "peak": None, "unit": "Ginst/s" if lds_tree else "Grequests/s", "frac": None,
+            "traffic": None,
+            "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
+            # the reading the metric's definition asks for
+            "algorithmic": {"achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                            "bytes_per_launch": int(alg_bytes / max(launches_per_frame, 1)),
+                            "bytes_per_segment": round(alg_bytes / max(counted.segments, 1), 1)},
+            "note": ("the interior records of this tree are staged in LDS by every workgroup, so the algorithmic "
+                     "bytes (32 B per node visited + ray, result and primitive records) never reach HBM; the "
+                     "counters show vector-instruction issue as the limit, and achieved / peak / frac are wave-level "
+                     "vector instructions per second against the rate measured on this chip (tools/valu_peak.hip)")
+            if lds_tree else
+                    ("every interior step is a dependent fetch of a 64-byte record from a table far larger than the "
+                     "caches; achieved / peak / frac are 64-byte requests leaving L2 per second against the rate "
+                     "measured for such reads on this chip (tools/gather_peak.hip); `algorithmic` counts every node "
+                     "visit although the top of the tree is served by L1 and L2"),
+        }
         out = {
             "metric": "Mrays/s", "value": round(segments / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "week.toml Next-Week scene %dx%d %d spp depth %d, %d primitives, "
-                                   "%d BVH nodes (SAH)" % (WIDTH, HEIGHT, args.spp, DEPTH, info.n_prims,
-                                                           info.n_nodes),
+            "config": {"workload": "%s %dx%d %d spp depth %d, %d primitives, %d BVH nodes (SAH)" % (
+                           cfg["label"], WIDTH, HEIGHT, args.spp, DEPTH, info.n_prims, info.n_nodes),
                        "sharding": "32x32 tiles round-robin over ranks, one reduce(sum) per frame",
                        "ray_segments_per_frame": int(segments / args.steps)},
-            "roofline": {"kernel": "k_bounce + k_bounce_loop",
-                         # the interior records of this tree are staged in LDS by every workgroup: the
-                         # algorithmic bytes are served by LDS, and the counters show vector-instruction
-                         # issue, not memory, as the limit (valu, below)
-                         "bound": "valu", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
-                         "algorithmic_bytes_per_launch": int(alg_bytes / max(launches_per_frame, 1)),
-                         "avg_launch_ms": round(per_launch_ms, 4),
-                         "launches_per_frame": launches_per_frame,
-                         "valu": None,
-                         "note": "achieved/peak/frac: algorithmic bytes (32 B per node visited + ray, result and "
-                                 "primitive records) over the HBM peak, as the metric is defined; the tree is "
-                                 "LDS resident, so this is not HBM traffic (see traffic) and the limit is "
-                                 "instruction issue (see valu)"},
+            "roofline": roofline,
             "host": host_info(),
         }
         # hardware counters of a rocprofv3 run on these very kernel sources (tools/profile_round.sh)
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_current.json")
-        if world == 1 and os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_current.json" if lds_tree else "pmc_current_c5.json")
+        if world == 1 and os.path.exists(pmc_file) and trace_ms > 0:
             with open(pmc_file) as f:
                 pmc = json.load(f)
             if pmc.get("source_hash") == kernel_source_hash() and pmc.get("spp") == args.spp:
-                out["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
                 v = pmc.get("valu")
                 if v:
                     seg = float(pmc.get("segments_per_frame", segments / args.steps))
-                    rate = v["wave_insts_per_frame"] / (trace_ms / args.steps * 1e-3)
-                    out["roofline"]["valu"] = {
+                    rate = v["wave_insts_per_frame"] / frame_trace_s / 1e9
+                    roofline["valu"] = {
                         "wave_insts_per_segment": round(v["wave_insts_per_frame"] / seg, 2),
-                        "achieved_ginst_s": round(rate / 1e9, 1), "peak_ginst_s": v["peak_ginst_s"],
-                        "frac": round(rate / 1e9 / v["peak_ginst_s"], 4),
+                        "achieved_ginst_s": round(rate, 1), "peak_ginst_s": v["peak_ginst_s"],
+                        "frac": round(rate / v["peak_ginst_s"], 4),
+                        "frac_vs_guide_peak": round(rate / GUIDE_ISSUE_PEAK_GINST_S, 4),
+                        "guide_peak_ginst_s": round(GUIDE_ISSUE_PEAK_GINST_S, 1),
                         "active_lane_frac": v.get("active_lane_frac"), "peak_basis": v.get("peak_basis"),
-                        "source": pmc.get("source", "profiles/pmc_current.json")}
+                        "source": pmc.get("source", "profiles/" + os.path.basename(pmc_file))}
+                    if lds_tree:
+                        roofline.update(achieved=round(rate, 1), peak=v["peak_ginst_s"],
+                                        frac=round(rate / v["peak_ginst_s"], 4))
+                g = pmc.get("l2_requests")
+                if g and not lds_tree:
+                    rate = g["ea_read_requests_per_frame"] / frame_trace_s / 1e9
+                    roofline.update(achieved=round(rate, 2), peak=GATHER_PEAK_GREC_S,
+                                    frac=round(rate / GATHER_PEAK_GREC_S, 4))
+                    roofline["l2"] = {"hit_rate": g.get("l2_hit_rate"),
+                                      "requests_beyond_l2_per_segment": round(g["ea_read_requests_per_frame"] / max(counted.segments, 1), 2),
+                                      "peak_basis": "dependent random reads of 64-byte records, table of the tree's size, "
+                                                    "6 waves per SIMD (tools/gather_peak.hip, profiles/r03_gather_peak.jsonl)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["host"]["cpu_threads_used"] = cpu["cores"]

@@ -119,6 +119,41 @@ struct DeviceBuffers {
     // tables or per-pixel samples of the camera sampler (grown on demand)
     void *sampler_mem = nullptr;
     size_t sampler_bytes = 0;
+    // Test and experiment hooks (environment), read once when the scene is placed on the device:
+    //   RT355_LOOP_FROM=<bounce>    the one-launch kernel takes over at this bounce
+    //   RT355_LOOP_BELOW=<rays>     ... or once fewer rays than this are queued (0: never)
+    //   RT355_LOOP_STEAL=0          its waves read their own sub-queue only
+    //   RT355_LOOP_TURN_LIMIT=<n>   its spin guard
+    //   RT355_TAIL_FILE=<path>      where a probe build writes its per-wave records
+    struct Hooks {
+        uint32_t loop_from = 0xffffffffu;
+        bool loop_below_set = false;
+        uint64_t loop_below = 0;
+        bool loop_steal = true;
+        uint32_t turn_limit = rt::kLoopTurnLimit;
+        std::string tail_file;
+        void read() {
+            if (const char *e = getenv("RT355_LOOP_FROM")) {
+                loop_from = (uint32_t)atoi(e);
+                loop_below_set = true;
+                loop_below = 0;
+            }
+            if (const char *e = getenv("RT355_LOOP_BELOW")) {
+                loop_below_set = true;
+                loop_below = strtoull(e, nullptr, 10);
+            }
+            if (const char *e = getenv("RT355_LOOP_STEAL")) loop_steal = atoi(e) != 0;
+            if (const char *e = getenv("RT355_LOOP_TURN_LIMIT")) turn_limit = (uint32_t)strtoul(e, nullptr, 10);
+            if (const char *e = getenv("RT355_TAIL_FILE")) tail_file = e;
+        }
+    } hooks;
+    // A frame enqueued without waiting for it (rt_render_dev with stats == NULL): the event that
+    // marks its end, and the word of pinned host memory its last copy brings the one-launch
+    // kernel's error flag to.  The next frame on this device waits for the event (the workspace
+    // is shared) and fails if the flag is set.
+    hipEvent_t pending_done = nullptr;
+    uint32_t *pending_error = nullptr; // hipHostMalloc
+    bool pending = false;
 };
 
 } // namespace
@@ -417,6 +452,11 @@ void release(DeviceBuffers &db) {
     for (void *p : db.shadow_allocs) (void)hipFree(p);
     db.shadow_allocs.clear();
     for (auto &kv : db.cursors) (void)hipFree(kv.second);
+    if (db.pending_done) (void)hipEventDestroy(db.pending_done);
+    if (db.pending_error) (void)hipHostFree(db.pending_error);
+    db.pending_done = nullptr;
+    db.pending_error = nullptr;
+    db.pending = false;
     db.allocs.clear();
     db.ws_allocs.clear();
     db.cursors.clear();
@@ -594,6 +634,7 @@ uint32_t cluster_records(const std::vector<rt_linear_node> &nodes, std::vector<u
 // primitives sit next to each other.
 int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     HIP_TRY(hipSetDevice(device));
+    db.hooks.read();
     const auto &nodes = s.tree.nodes;
     // records are numbered in the pre-order of the flattened tree (bvh.rs:661-691)
     std::vector<uint32_t> record_of(nodes.size(), 0);
@@ -1620,21 +1661,33 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     // then, with no round trip to the host in the middle of a frame.
     // RT355_LOOP_FROM=<bounce> fixes the bounce instead, RT355_LOOP_BELOW=<rays> the threshold
     // (0: never), for tests and experiments.
-    uint32_t loop_from = 0xffffffffu;
-    uint64_t loop_below = db->shape.lds_nodes ? (8u << 20) : (2u << 20);
-    if (const char *e = getenv("RT355_LOOP_FROM")) {
-        loop_from = (uint32_t)atoi(e);
-        loop_below = 0;
-    }
-    if (const char *e = getenv("RT355_LOOP_BELOW")) loop_below = strtoull(e, nullptr, 10);
-    // RT355_LOOP_STEAL=0: a wave of that launch reads its own sub-queue only (experiments)
-    const char *ls = getenv("RT355_LOOP_STEAL");
-    const bool loop_steal = !(ls && atoi(ls) == 0);
-    // RT355_LOOP_TURN_LIMIT=<turns>: test hook for the spin guard of that launch
-    uint32_t turn_limit = rt::kLoopTurnLimit;
-    if (const char *e = getenv("RT355_LOOP_TURN_LIMIT")) turn_limit = (uint32_t)strtoul(e, nullptr, 10);
+    // The hooks that fix the bounce or the threshold instead were read when the scene was placed
+    // on the device (DeviceBuffers::Hooks).
+    const DeviceBuffers::Hooks &hooks = db->hooks;
+    const uint32_t loop_from = hooks.loop_from;
+    const uint64_t loop_below = hooks.loop_below_set ? hooks.loop_below : (db->shape.lds_nodes ? (8u << 20) : (2u << 20));
+    const bool loop_steal = hooks.loop_steal;
+    const uint32_t turn_limit = hooks.turn_limit;
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
     const bool want_timing = (o->flags & RT_RENDER_TIMING) != 0;
+    // A frame the caller does not want statistics of is enqueued and not waited for (below).  The
+    // frame before it on this device may have been one of those: wait for it now, since both use
+    // the same workspace, and report the error its one-launch kernel may have flagged.
+    const bool no_wait = stats == nullptr;
+    if (db->pending) {
+        HIP_TRY(hipEventSynchronize(db->pending_done));
+        db->pending = false;
+        if (*db->pending_error) {
+            *db->pending_error = 0;
+            return fail(RT_ERR_LIMIT, "a wave of the path kernel exceeded its feed turns in the frame before this one "
+                                      "(enqueued without statistics): that frame is incomplete");
+        }
+    }
+    if (no_wait && !db->pending_done) {
+        HIP_TRY(hipEventCreateWithFlags(&db->pending_done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **)&db->pending_error, sizeof(uint32_t), hipHostMallocDefault));
+        *db->pending_error = 0;
+    }
     EventList events; // destroyed on every way out
     std::vector<hipEvent_t> &ev = events.timed;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -1711,6 +1764,13 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             HIP_TRY(rt::launch_resolve(F, db->radiance, n_ranks, sc, s0 + sc >= o->spp ? 1 : 0,
                                        reinterpret_cast<float4 *>(d_rgba), st));
         }
+        if (no_wait && switched_at == 0xffffffffu) {
+            // nobody asked for this batch's counts: only the error flag travels, behind everything
+            // else, and is looked at by the next call on this device
+            HIP_TRY(hipMemcpyAsync(db->pending_error, db->counts + rt::kLoopErrorWord, sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
+            continue;
+        }
         // queue sizes of this batch = ray segments traced per bounce
         HIP_TRY(hipMemcpyAsync(counts.data(), db->counts, counts.size() * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
@@ -1734,6 +1794,11 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 for (uint32_t k = 0; k < rt::kShards; k++)
                     occlusion += scounts[((size_t)b * rt::kShards + k) * rt::kCountStride];
         }
+    }
+    if (no_wait) {
+        HIP_TRY(hipEventRecord(db->pending_done, st));
+        db->pending = true;
+        return RT_OK;
     }
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipEventSynchronize(ev_end));
@@ -1770,8 +1835,8 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                     std::vector<unsigned long long> rec((size_t)waves * 5);
                     HIP_TRY(hipMemcpy2D(rec.data(), 40, db->bounce_scratch, rt::kWaveLoopBytes, 40, waves,
                                         hipMemcpyDeviceToHost));
-                    if (const char *f = getenv("RT355_TAIL_FILE")) {
-                        if (FILE *out = fopen(f, "w")) {
+                    if (!hooks.tail_file.empty()) {
+                        if (FILE *out = fopen(hooks.tail_file.c_str(), "w")) {
                             const unsigned long long t0 = ~tp[0];
                             for (uint32_t w = 0; w < waves; w++) {
                                 const unsigned long long *r = &rec[(size_t)w * 5];
@@ -1807,7 +1872,8 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, float 
     const size_t bytes = (size_t)o->width * o->height * 4 * sizeof(float);
     float *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, bytes ? bytes : 16));
-    rc = rt_render_dev(s, cam, o, d, stats, device, nullptr);
+    rt_stats waited; // statistics asked for = the call waits for the frame and reports its errors
+    rc = rt_render_dev(s, cam, o, d, stats ? stats : &waited, device, nullptr);
     if (rc == RT_OK && hipMemcpy(rgba, d, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(RT_ERR_HIP, "framebuffer download failed");
     (void)hipFree(d);

@@ -168,7 +168,12 @@ class Scene:
                                   self.device))
         return img, st
 
-    def render_dev(self, cam, opts, rgba_ptr, stream=None):
+    def render_dev(self, cam, opts, rgba_ptr, stream=None, want_stats=True):
+        """want_stats=False: the frame is enqueued on `stream` and not waited for (rt_render_dev
+        with stats == NULL); returns None."""
+        if not want_stats:
+            check(self._lib.rt_render_dev(self._h, C.byref(cam), C.byref(opts), rgba_ptr, None, self.device, stream))
+            return None
         st = abi.rt_stats()
         check(self._lib.rt_render_dev(self._h, C.byref(cam), C.byref(opts), rgba_ptr, C.byref(st),
                                       self.device, stream))

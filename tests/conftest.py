@@ -53,3 +53,16 @@ def scene_cache():
         return cache[key]
 
     return get
+
+
+def scene_with_hooks(monkeypatch, frozen, *args, **env):
+    """A library scene built and placed on the device while the given RT355_* test hooks are set
+    (the library reads them once, at that moment; later changes of the environment do nothing)."""
+    from raytracer_amd import lib
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    g = lib.Scene(frozen, *args)
+    g.upload()
+    for k in env:
+        monkeypatch.delenv(k)
+    return g

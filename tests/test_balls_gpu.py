@@ -11,7 +11,7 @@ import pytest
 from raytracer_amd import abi, lib
 from raytracer_amd.scene import look_at, perspective_camera
 from tests import orc
-from tests.conftest import random_rays
+from tests.conftest import random_rays, scene_with_hooks
 from tests.mixed import ball_scene, rays_inside
 from tests.test_parity_gpu import assert_hits_equal
 
@@ -48,11 +48,10 @@ def test_rays_from_inside_the_balls(monkeypatch, nodes, seed, max_prims, split):
 def test_frames_through_the_balls(monkeypatch, nodes, loop_from):
     if nodes == "global":
         monkeypatch.setenv("RT355_NODES", "global")
-    if loop_from is not None:
-        monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
     sd, balls = ball_scene(seed=7)
     fr = sd.freeze()
-    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    g = scene_with_hooks(monkeypatch, fr, **({} if loop_from is None else {"RT355_LOOP_FROM": loop_from}))
+    o = orc.OracleScene(fr)
     w, h = 96, 64
     for eye, at in (((30.0, 2.0, 18.0), balls[0][0]), ((-30.0, 6.0, 14.0), balls[1][0]), ((4.0, -30.0, 16.0), balls[3][0])):
         cam = perspective_camera(w, h, 45.0, look_at(eye, at, (0.0, 1.0, 0.0)))

@@ -10,7 +10,7 @@ import pytest
 
 from raytracer_amd import abi, lib
 from tests import orc
-from tests.conftest import random_rays
+from tests.conftest import scene_with_hooks, random_rays
 from tests.mixed import mixed_scene
 
 pytestmark = pytest.mark.gpu
@@ -268,12 +268,11 @@ def test_paths_followed_in_one_launch(monkeypatch, scene_cache, scene_name, loop
     g, o = lib.Scene(fr), orc.OracleScene(fr)
     w, h, spp, depth = 160, 96, 3, 50
     ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
-    monkeypatch.setenv("RT355_LOOP_BELOW", "0")  # one launch per bounce
-    base, bst = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
-    monkeypatch.delenv("RT355_LOOP_BELOW")
+    per_bounce = scene_with_hooks(monkeypatch, fr, RT355_LOOP_BELOW=0)  # one launch per bounce
+    base, bst = per_bounce.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
     auto, ast = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5))  # the library decides (small frame)
     assert ast.trace_launches < depth and auto.tobytes() == base.tobytes() and ast.segments == bst.segments
-    monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
+    g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=loop_from)
     img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=5, flags=abi.RT_RENDER_COUNTERS))
     assert st.trace_launches == loop_from + 1 and bst.trace_launches == depth
     assert img.tobytes() == ref.tobytes() == base.tobytes()
@@ -300,9 +299,8 @@ def test_one_launch_kernel_with_film_sampler_and_shards(monkeypatch, scene_cache
     for nodes in ("lds", "global"):
         if nodes == "global":
             monkeypatch.setenv("RT355_NODES", "global")
-        g = lib.Scene(fr)
         for loop_from in (1, 3):
-            monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
+            g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=loop_from)
             img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, 30, max_paths=6 * 1024 * 2, **kw))
             assert st.batches == 2 and img.tobytes() == ref.tobytes() and st.segments == rst.segments
         parts = [g.render(cam(w, h), lib.render_opts(w, h, spp, 30, seed=2, shard=(k, 3)))[0] for k in range(3)]
@@ -319,17 +317,15 @@ def test_one_launch_kernel_shares_sub_queues(monkeypatch, scene_cache, nodes):
     if nodes == "global":
         monkeypatch.setenv("RT355_NODES", "global")
     _, cam, fr = scene_cache("week")
-    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    o = orc.OracleScene(fr)
     w, h, spp, depth = 320, 200, 16, 50
     ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=9))
-    monkeypatch.setenv("RT355_LOOP_BELOW", "0")
+    g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_BELOW=0)
     base, bst = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=9))
-    monkeypatch.delenv("RT355_LOOP_BELOW")
     assert base.tobytes() == ref.tobytes() and bst.segments == rst.segments
     for loop_from in (0, 1, 3):
-        monkeypatch.setenv("RT355_LOOP_FROM", str(loop_from))
         for steal in ("1", "0"):
-            monkeypatch.setenv("RT355_LOOP_STEAL", steal)
+            g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=loop_from, RT355_LOOP_STEAL=steal)
             img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=9))
             assert st.trace_launches == loop_from + 1
             assert img.tobytes() == ref.tobytes(), (loop_from, steal)
@@ -360,10 +356,10 @@ def test_paths_deeper_than_a_byte_counts(monkeypatch, scene_cache):
     findings; depths above 255 must not wrap (week.toml's fog-filled ball keeps paths alive that
     long).  Beyond 16 bits the call is refused."""
     _, cam, fr = scene_cache("week")
-    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    o = orc.OracleScene(fr)
     w, h, spp, depth = 64, 48, 2, 300
     ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=6))
-    monkeypatch.setenv("RT355_LOOP_FROM", "2")
+    g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=2)
     img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=6))
     assert st.trace_launches == 3 and st.max_bounce > 256  # some paths do get that deep
     assert img.tobytes() == ref.tobytes() and st.segments == rst.segments
@@ -377,15 +373,21 @@ def test_spin_guard_of_the_one_launch_kernel_is_reported(monkeypatch, scene_cach
     feed turns and drops its segments; the call must then fail instead of returning the
     incomplete frame.  Forced here with a limit of three turns."""
     _, cam, fr = scene_cache("week")
-    g, o = lib.Scene(fr), orc.OracleScene(fr)
+    o = orc.OracleScene(fr)
     w, h, spp = 96, 64, 4
-    monkeypatch.setenv("RT355_LOOP_FROM", "1")
-    monkeypatch.setenv("RT355_LOOP_TURN_LIMIT", "3")
+    g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=1, RT355_LOOP_TURN_LIMIT=3)
     with pytest.raises(lib.RtError) as e:
         g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=4))
     assert e.value.code == abi.RT_ERR_LIMIT and "incomplete" in str(e.value)
-    monkeypatch.delenv("RT355_LOOP_TURN_LIMIT")
-    img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=4))  # the scene is still usable
+    # frames enqueued without statistics are not waited for: the next call on the device reports it
+    import torch
+    d_img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    g.render_dev(cam(w, h), lib.render_opts(w, h, spp, 50, seed=4), d_img.data_ptr(), want_stats=False)
+    with pytest.raises(lib.RtError) as e:
+        g.render(cam(w, h), lib.render_opts(w, h, spp, 2, seed=4))
+    assert e.value.code == abi.RT_ERR_LIMIT and "frame before" in str(e.value)
+    g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=1)
+    img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, 50, seed=4))
     ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, 50, seed=4))
     assert img.tobytes() == ref.tobytes() and st.segments == rst.segments
 

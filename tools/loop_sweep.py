@@ -7,7 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracer_amd import abi, lib, scenes
 sd, camf = scenes.BUILDERS["week"]()
-g = lib.Scene(sd.freeze(), 4, 0)
+fr = sd.freeze()
+def scene():  # the hooks are read when a scene is placed on the device
+    g = lib.Scene(fr, 4, 0)
+    g.upload()
+    return g
+g = scene()
 w, h = 1920, 1080
 fb = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
@@ -22,10 +27,12 @@ def t(o, n=4):
 for n in (1, 8, 4, 2):
     o = lib.render_opts(w, h, 64, 50, seed=0, shard=(0, n))
     os.environ.pop("RT355_LOOP_FROM", None); os.environ.pop("RT355_LOOP_BELOW", None)
+    g = scene()
     ms, s = t(o)
     print("shards %d auto: %.2f ms launches %d rays %s" % (n, ms, s.trace_launches, list(s.bounce_rays[:10])), flush=True)
     for f in (1, 2, 3, 4, 6, 8, 12, 16, 24):
         os.environ["RT355_LOOP_FROM"] = str(f)
+        g = scene()
         ms, s = t(o)
         print("shards %d from %d: %.2f ms" % (n, f, ms), flush=True)
     os.environ.pop("RT355_LOOP_FROM", None)

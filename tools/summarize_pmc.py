@@ -23,6 +23,8 @@ wanted = match.split(",")
 traffic_out = sys.argv[sys.argv.index("--current") + 1] if "--current" in sys.argv else None
 spp = int(sys.argv[sys.argv.index("--spp") + 1]) if "--spp" in sys.argv else 64
 args = [a for a in args if a != traffic_out and a != str(spp)]
+# --raw-fetch: FETCH_SIZE as counted (kernels whose reads are mostly 64-byte gathers, which are tallied in full)
+fetch_factor = 1 if "--raw-fetch" in sys.argv else 2
 tot = collections.defaultdict(float)
 disp = collections.defaultdict(set)
 for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True)):
@@ -53,7 +55,7 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     d["fetch_bytes_raw"] = c["FETCH_SIZE"] * 1024
     d["fetch_bytes_corrected_x2"] = c["FETCH_SIZE"] * 2048
     d["write_bytes"] = c["WRITE_SIZE"] * 1024
-    d["hbm_bytes_per_launch"] = (c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024) / max(n, 1)
+    d["hbm_bytes_per_launch"] = (c["FETCH_SIZE"] * 1024 * fetch_factor + c["WRITE_SIZE"] * 1024) / max(n, 1)
     if traffic_out:
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -64,10 +66,15 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # 2.3 GHz the chip holds under that load); v_max, v_mul_lo_u32 take 4.2, v_rcp 8.2.
         cur = {"source_hash": bench.kernel_source_hash(), "spp": spp, "kernel": match, "launches_per_frame": n,
                "fetch_KiB_raw": c["FETCH_SIZE"], "write_KiB": c["WRITE_SIZE"],
-               "correction": "FETCH_SIZE x2 (gfx950: 128-byte requests of 16-B-per-lane streaming reads are tallied "
-                             "at 64 bytes; an upper bound here, part of the reads are 16-byte gathers); WRITE_SIZE as is",
+               "correction": ("FETCH_SIZE x2 (gfx950: 128-byte requests of 16-B-per-lane streaming reads are tallied "
+                              "at 64 bytes; an upper bound here, part of the reads are 16-byte gathers); WRITE_SIZE as is")
+               if fetch_factor == 2 else
+                             ("FETCH_SIZE as counted (the reads are mostly gathers of 64-byte records, tallied in full; "
+                              "the queues' streaming reads, a few per cent of the requests, are under-counted by half: "
+                              "a lower bound); WRITE_SIZE as is"),
                "hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]),
-               "source": "profiles/pmc_current.json (rocprofv3 --pmc passes of bench.py --steps 1 --warmup 0, tools/profile_round.sh)"}
+               "source": "profiles/%s (rocprofv3 --pmc passes of bench.py --steps 1 --warmup 0, tools/profile_round.sh)"
+                         % os.path.basename(traffic_out)}
         if c.get("SQ_INSTS_VALU"):
             cur["valu"] = {"wave_insts_per_frame": c["SQ_INSTS_VALU"], "salu_insts_per_frame": c.get("SQ_INSTS_SALU"),
                            "peak_ginst_s": 950.0,
@@ -75,6 +82,11 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                                          "tools/valu_peak.hip (profiles/r02_valu_peak.jsonl)",
                            "active_lane_frac": round(d.get("valu_active_lane_frac", 0.0), 4),
                            "wait_any_frac": round(d.get("wait_any_frac", 0.0), 4)}
+        if c.get("TCC_EA0_RDREQ_sum"):
+            # 64-byte read requests that leave L2 (to the Infinity Cache and HBM): what a traversal of a tree
+            # in global memory is limited by
+            cur["l2_requests"] = {"ea_read_requests_per_frame": c["TCC_EA0_RDREQ_sum"],
+                                  "l2_hit_rate": round(d.get("l2_hit_rate", 0.0), 4)}
         json.dump(cur, open(traffic_out, "w"), indent=1)
 out["derived"] = d
 print(json.dumps(out, indent=1))
