@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--checksum", action="store_true", help="print a checksum of the final frame to stderr")
+    ap.add_argument("--no-wait", action="store_true",
+                    help="nccl backend only: frames are enqueued without statistics and not waited for, so that "
+                         "the frame's reduce follows its kernels on the stream without a host round trip")
     ap.add_argument("--single-rank-collective", action="store_true",
                     help="rehearsal only: a world of one still joins the process group and runs the frame's "
                          "reduce, the barriers and the all-reduces through the backend (RCCL with one rank)")
@@ -217,14 +220,17 @@ def main():
     for _ in range(args.warmup):
         frame()
     fence()
-    # One rank: every timed frame carries HIP events around its bounce launches (what the roofline's
-    # kernel time is made of) and is waited for.  Ranks joined by RCCL: a rank enqueues frame and
-    # reduce on its stream without waiting in between -- its segment count is that of the counting
-    # frame, the scene and the seed being the same -- and one more frame after the timed region
-    # takes the kernel times.  (The gloo rehearsal, where ranks share one GPU, waits for every frame:
-    # gloo stages through the host anyway, and two processes that both keep a deep queue of
-    # persistent kernels on one device were seen to stall each other.)
-    wait_frames = not (use_dist and args.backend == "nccl")
+    # Every timed frame carries HIP events around its bounce launches (what the roofline's kernel
+    # time is made of) and is waited for before its reduce is enqueued.  --no-wait (ranks joined by
+    # RCCL only): a rank enqueues frame and reduce on its stream without a host wait in between --
+    # its segment count is that of the counting frame, the scene and the seed being the same -- and
+    # one more frame after the timed region takes the kernel times.  It saves one host round trip
+    # per frame (tens of microseconds) and has only been run with one rank, no node with several
+    # GPUs having been at hand; with gloo, whose reduce stages through the host, two ranks sharing
+    # one GPU stalled in it, so there it is refused.
+    if args.no_wait and not (use_dist and args.backend == "nccl"):
+        sys.exit("--no-wait needs ranks joined by the nccl backend")
+    wait_frames = not args.no_wait
     t0 = time.perf_counter()
     segments = 0
     trace_ms = 0.0

@@ -655,8 +655,9 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     const char *force = getenv("RT355_NODES"); // "global": override for experiments
     bool lds_nodes = false;
     uint32_t stack_lds = 0;
-    if (n_pairs > 0 && n_pairs < 0x8000u && s.prims.size() < 0x8000u && (size_t)n_pairs * 64 < lds_cu) {
-        const size_t room = lds_cu - (size_t)n_pairs * 64;
+    constexpr size_t kDump = 256; // where prefetches land (rt::lds_bytes adds it)
+    if (n_pairs > 0 && n_pairs < 0x8000u && s.prims.size() < 0x8000u && (size_t)n_pairs * 64 + kDump < lds_cu) {
+        const size_t room = lds_cu - (size_t)n_pairs * 64 - kDump;
         stack_lds = (uint32_t)std::min<size_t>(slots, room / (1024 * 6));
         lds_nodes = stack_lds >= std::min(slots, kMinLds);
     }
@@ -1781,6 +1782,19 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         if (counts[rt::kLoopErrorWord])
             return fail(RT_ERR_LIMIT, "a wave of the path kernel exceeded %u feed turns and dropped its segments: "
                                       "the frame is incomplete", turn_limit);
+        if (hinted && loop_below) {
+            // Does the remembered bounce still fit?  Another camera or seed may have changed how fast the
+            // queue shrinks: the kernel that follows paths to their end should take over at the first of
+            // the bounces 2, 4, 8, ... whose queue is below the threshold.  If it did not, the next frame
+            // of this shape looks again.
+            auto queued_at = [&](uint32_t b) {
+                uint64_t q = 0;
+                for (uint32_t k = 0; k < rt::kShards; k++) q += counts[((size_t)b * rt::kShards + k) * rt::kCountStride];
+                return q;
+            };
+            const uint32_t at = hint.bounce;
+            if (queued_at(at) >= loop_below || (at >= 4 && queued_at(at / 2) < loop_below)) hint.valid = false;
+        }
         const uint64_t live = (uint64_t)owned_pixels * sc; // entries of bounce 0 that are not padding
         paths += live;
         for (uint32_t b = 0; b < o->max_depth; b++) {

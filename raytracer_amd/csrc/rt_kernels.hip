@@ -85,7 +85,7 @@ struct TreeView {
     typename Shape<LDSN>::RefT *ref; // stack part in LDS: ref[level * kThreads], near[level * kThreads]
     float *near;
     uint32_t levels;     // stack levels kept in LDS
-    float *dump;         // !LDSN: 256 bytes behind the stacks where prefetches of far children land (never read)
+    float *dump;         // 256 bytes behind the stacks where prefetches land (never read)
 };
 
 // Carves the dynamic LDS; with LDSN also stages the records (call from all threads).
@@ -112,7 +112,9 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
     v.ref = reinterpret_cast<typename Shape<LDSN>::RefT *>(reinterpret_cast<float *>(base) +
                                                             (size_t)S.stack_lds * kThreads) +
             threadIdx.x;
-    v.dump = LDSN ? nullptr : reinterpret_cast<float *>(base) + 2 * (size_t)S.stack_lds * kThreads;
+    // behind the stacks: near (4 bytes) and ref (RefT) per level and thread
+    v.dump = reinterpret_cast<float *>(reinterpret_cast<char *>(base) +
+                                       (size_t)S.stack_lds * kThreads * (sizeof(float) + sizeof(typename Shape<LDSN>::RefT)));
     return v;
 }
 
@@ -1555,6 +1557,23 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
 // rather than whenever one ray of a wave does.  The lanes' traversal state is
 // written to memory around a shading batch and read back after it, so shading and
 // traversal do not compete for registers.
+// Asks for the lines of a queue block (64 entries from `first`) without waiting for them: the loads
+// land in a dump area in LDS that nobody reads.  A wave claims its next block a whole feed turn
+// before it hands out that block's rays, and the queue was written by the launch before, so without
+// this every hand-out and every shading batch waits for memory the wave could have asked for long ago.
+RT_DEV void prefetch_block(const Queue &q, size_t first, bool with_e, float *dump) {
+    const uint32_t lane = threadIdx.x & 63;
+    auto touch = [&](const void *p) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                         (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
+    };
+    touch(q.a + first + lane);
+    touch(q.b + first + lane);
+    touch(q.c + first + lane);
+    touch(q.d + first + lane);
+    if (with_e) touch(q.e + first + lane);
+}
+
 template <bool NEE>
 struct BounceFeed {
     static constexpr bool kPretested = true;
@@ -1576,6 +1595,7 @@ struct BounceFeed {
     uint32_t *stail;
     size_t shadow_base; // first entry of the shadow sub-queue written (its own capacity, not qout's)
     uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
+    float *dump = nullptr; // where prefetches land (LDS)
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     PROF(unsigned long long prof_take = 0; unsigned long long prof_load = 0; unsigned long long prof_park = 0;)
     RT_DEV bool more() const { return blocks.more(); }
@@ -1734,7 +1754,14 @@ struct BounceFeed {
         }
         PROF(const unsigned long long prof_t1 = __builtin_amdgcn_s_memtime(); prof_shade += prof_t1 - prof_t0;)
         // next rays
+#ifdef RT_PREFETCH_QUEUE
+        const uint32_t blk_before = blocks.blk;
+#endif
         const uint32_t next = blocks.take(free);
+#ifdef RT_PREFETCH_QUEUE
+        if (blocks.blk != blk_before && blocks.more())
+            prefetch_block(qin, in_base + blocks.base + blocks.blk, (S.n_enclosing | S.n_balls) != 0, dump);
+#endif
         PROF(const unsigned long long prof_t2 = __builtin_amdgcn_s_memtime(); prof_take += prof_t2 - prof_t1;)
         bool fresh = false;
         if (free) {
@@ -1815,6 +1842,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u, sq,
                     NEE ? scounts + ((size_t)bounce * kShards + shard) * kCountStride : nullptr,
                     (size_t)shard * sq.cap};
+    feed.dump = tv.dump;
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
@@ -1925,6 +1953,7 @@ struct LoopFeed {
     uint32_t parked[2];
     uint32_t ring_head, ring_count, turns, turn_limit;
     uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
+    float *dump = nullptr; // where prefetches land (LDS)
     Counters *cnt = nullptr; // counting launches: where segments shaded without a traversal are counted
 #ifdef RT_TAIL_PROBE
     unsigned long long probe_dry = 0; // clock when this wave first found the queue read out
@@ -2124,7 +2153,14 @@ struct LoopFeed {
         const uint32_t rank = lane_rank(want);
         const uint32_t from_ring = min((uint32_t)__popcll(want), ring_count);
         const bool ring_lane = free && rank < from_ring;
+#ifdef RT_PREFETCH_QUEUE
+        const uint32_t blk_before = blocks.blk, base_before = blocks.base;
+#endif
         const uint32_t next = blocks.take(free && !ring_lane);
+#ifdef RT_PREFETCH_QUEUE
+        if ((blocks.blk != blk_before || blocks.base != base_before) && blocks.more())
+            prefetch_block(qin, in_base + blocks.base + blocks.blk, (S.n_enclosing | S.n_balls) != 0, dump);
+#endif
         bool fresh = false;
         if (free) {
             L.has_ray = false;
@@ -2242,6 +2278,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
                   {0u, 0u}, 0u, 0u, 0u, turn_limit};
     if (COUNT) feed.cnt = &cnt;
+    feed.dump = tv.dump;
     feed.blocks.start();
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
@@ -2372,8 +2409,8 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(float4 *rgba, size_t n)
 // dynamic LDS: the LDS part of the stacks (child reference + entry distance per level and
 // lane), preceded by the interior records for the LDS-resident shape
 size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds) {
-    return lds_nodes ? (size_t)n_pairs * 64 + (size_t)stack_lds * 1024 * (sizeof(float) + sizeof(uint16_t))
-                     : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t)) + 256; // + the prefetch dump
+    return (lds_nodes ? (size_t)n_pairs * 64 + (size_t)stack_lds * 1024 * (sizeof(float) + sizeof(uint16_t))
+                      : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t))) + 256; // + the prefetch dump
 }
 
 template <class K>

@@ -51,3 +51,8 @@ def test_one_rank_through_rccl():
     assert sha1 == sha2
     assert rccl["n_gpus"] == 1
     assert rccl["config"]["ray_segments_per_frame"] == one["config"]["ray_segments_per_frame"]
+    # frames enqueued without a host wait, the reduce right behind them on the stream
+    fast, sha3 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                      "--master-addr", "127.0.0.1", "--master-port", "29535", "bench.py", "--gpus", "1",
+                      "--single-rank-collective", "--no-wait"] + COMMON)
+    assert sha3 == sha1 and fast["config"]["ray_segments_per_frame"] == one["config"]["ray_segments_per_frame"]

@@ -351,6 +351,31 @@ def test_switch_bounce_is_remembered_between_frames(scene_cache):
     assert third.tobytes() == ref9.tobytes()
 
 
+def test_switch_bounce_is_looked_up_again_when_it_no_longer_fits(monkeypatch, scene_cache):
+    """The remembered bounce belongs to a frame shape, not to a camera: when a frame of the same
+    shape shrinks its queues faster (here: a camera that looks past the scene), the counts that come
+    back with it show that the switch could have come earlier, and the next frame looks again."""
+    from raytracer_amd.scene import look_at, perspective_camera
+    _, cam, fr = scene_cache("week")
+    o = orc.OracleScene(fr)
+    w, h, spp = 160, 96, 3
+    g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_BELOW=12000)
+    opts = lib.render_opts(w, h, spp, 50, seed=8)
+    first, fst = g.render(cam(w, h), opts)
+    assert fst.bounce_rays[2] >= 12000 > fst.bounce_rays[4] and fst.trace_launches == 5  # bounces 0-3, then the rest
+    away = perspective_camera(w, h, 40.0, look_at((478.0, 278.0, -600.0), (478.0, 278.0, -1200.0), (0.0, 1.0, 0.0)))
+    a, ast = g.render(away, opts)
+    assert ast.bounce_rays[2] < 12000 and ast.trace_launches == 5  # most paths have left by bounce 2; switched where the frame before did
+    b, bst = g.render(away, opts)
+    assert bst.trace_launches == 3  # looked again: bounces 0 and 1, then the rest
+    ref, _ = o.render(away, orc.render_opts(w, h, spp, 50, seed=8))
+    assert a.tobytes() == b.tobytes() == ref.tobytes()
+    again, gst = g.render(cam(w, h), opts)  # and back: the queue at bounce 2 is too large again
+    assert gst.trace_launches == 3 and again.tobytes() == first.tobytes()
+    last, lst = g.render(cam(w, h), opts)
+    assert lst.trace_launches == 5 and last.tobytes() == first.tobytes()
+
+
 def test_paths_deeper_than_a_byte_counts(monkeypatch, scene_cache):
     """The one-launch kernel carries a segment's depth through its ring beside the producer's
     findings; depths above 255 must not wrap (week.toml's fog-filled ball keeps paths alive that

@@ -117,3 +117,29 @@ def test_full_size_synthetic_scene_properties(scene_cache):
     second = bounce_rays(primary, ref, 9)
     assert_same_hits(g.intersect(second), o.intersect(second, threads=16), "bounce 1, full size")
     assert (g.does_intersect(second) == o.occluded(second, threads=16)).all()
+
+
+@pytest.mark.parametrize("cluster", ["7,8", "16", "3,4"])
+def test_record_layout_does_not_change_results(monkeypatch, scene_cache, cluster):
+    """The interior records of a tree in global memory may be laid out in clusters
+    (RT355_NODE_CLUSTER = size[,alignment]) instead of the flattened tree's pre-order: record
+    numbers are internal to the device tables, so hits, any-hit bytes, counters and frames stay
+    those of the oracle, and rt_scene_get_nodes still returns the reference's order."""
+    sd, cam = scenes.BUILDERS["synthetic"](grid=48, n_spheres=20000)
+    fr = sd.freeze()
+    monkeypatch.setenv("RT355_NODES", "global")
+    monkeypatch.setenv("RT355_NODE_CLUSTER", cluster)
+    g, o = lib.Scene(fr, 4, abi.RT_SPLIT_SAH), orc.OracleScene(fr, 4, abi.RT_SPLIT_SAH)
+    assert g.nodes().tobytes() == o.nodes().tobytes()
+    w, h = 192, 108
+    c = cam(w, h)
+    primary = lib.generate_rays(c, lib.render_opts(w, h, 1, seed=1), 0, w * h)
+    ref, ref_counters = o.intersect(primary, counters=True)
+    assert_same_hits(g.intersect(primary), ref, "clustered records, primary")
+    second = bounce_rays(primary, ref, 3)
+    assert_same_hits(g.intersect(second), o.intersect(second), "clustered records, bounce 1")
+    assert (g.does_intersect(second) == o.occluded(second)).all()
+    img, st = g.render(c, lib.render_opts(w, h, 2, 8, seed=2, flags=abi.RT_RENDER_COUNTERS))
+    want, wst = o.render(c, orc.render_opts(w, h, 2, 8, seed=2, flags=abi.RT_RENDER_COUNTERS))
+    assert img.tobytes() == want.tobytes() and st.segments == wst.segments
+    assert st.nodes_visited == wst.nodes_visited and list(st.prims_tested) == list(wst.prims_tested)

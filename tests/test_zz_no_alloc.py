@@ -46,6 +46,17 @@ def test_no_alloc_entry_point_matches_intersect_dev(monkeypatch, scene_cache, no
         d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
         want = _device_hits(g, g.intersect_dev, d_rays, n, stream)
         got = _device_hits(g, g.intersect_dev_noalloc, d_rays, n, stream)
+        # ... and it really allocates nothing: free device memory is the same before and after two
+        # calls on buffers that exist already (the runtime reports whole bytes of the device)
+        d_hits = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
+        for _ in range(2):
+            g.intersect_dev_noalloc(d_rays.data_ptr(), n, d_hits.data_ptr(), stream)
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, (free_before, free_after)
+        assert d_hits.cpu().numpy().view(abi.hit_dtype).reshape(-1).tobytes() == want.tobytes()
         assert (want["prim"] != abi.RT_MISS).mean() > 0.2
         assert got.tobytes() == want.tobytes(), "%s n=%d" % (nodes, n)
         assert got.tobytes() == o.intersect(rays).tobytes()

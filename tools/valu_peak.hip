@@ -16,6 +16,10 @@ __global__ __launch_bounds__(64) void k_stream(float *out, unsigned long long *c
     float a[kAcc];
     for (int i = 0; i < kAcc; i++) a[i] = seed + (float)(threadIdx.x + i);
     const float m = 1.0000001f, c = 1e-9f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pk[kAcc / 2];
+    for (int i = 0; i < kAcc / 2; i++) pk[i] = f2{seed + (float)(threadIdx.x + i), seed + 0.5f};
+    const f2 pm = {m, m}, pc = {c, c};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < kIters; it++) {
 #pragma unroll
@@ -28,11 +32,16 @@ __global__ __launch_bounds__(64) void k_stream(float *out, unsigned long long *c
             if (KIND == 5) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if (KIND == 7) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            // packed fp32: two lanes' worth of results per lane and instruction (register pairs)
+            if (KIND == 8 && (i & 1) == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i / 2]) : "v"(pm));
+            if (KIND == 9 && (i & 1) == 0) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[i / 2]) : "v"(pc));
+            if (KIND == 10 && (i & 1) == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[i / 2]) : "v"(pm), "v"(pc));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.0f;
     for (int i = 0; i < kAcc; i++) s += a[i];
+    for (int i = 0; i < kAcc / 2; i++) s += pk[i].x + pk[i].y;
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         clocks[0] = t1 - t0;
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(64) void k_stream(float *out, unsigned long long *c
 }
 
 template <int KIND>
-static void run(const char *name, int insts_per_step, int cus, float *out, unsigned long long *clocks) {
+static void run(const char *name, double insts_per_step, int cus, float *out, unsigned long long *clocks) {
     for (int per_simd : {1, 2, 4, 8}) {
         const int waves = cus * 4 * per_simd;
         hipEvent_t e0, e1;
@@ -84,5 +93,9 @@ int main() {
     run<5>("v_mul_lo_u32", 1, cus, out, clocks);
     run<6>("v_rcp_f32", 1, cus, out, clocks);
     run<7>("v_and_b32", 1, cus, out, clocks);
+    // packed instructions: half as many per step (each does the work of two plain ones)
+    run<8>("v_pk_mul_f32", 0.5, cus, out, clocks);
+    run<9>("v_pk_add_f32", 0.5, cus, out, clocks);
+    run<10>("v_pk_fma_f32", 0.5, cus, out, clocks);
     return 0;
 }
