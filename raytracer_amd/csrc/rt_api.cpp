@@ -922,7 +922,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     memcpy(D.background, s.background, sizeof D.background);
 
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&p, rt::kCounterWords * sizeof(unsigned long long)));
     db.allocs.push_back(p);
     db.counters = static_cast<unsigned long long *>(p);
 
@@ -1266,7 +1266,7 @@ int rt_intersect_count(rt_scene *s, const rt_ray *d_rays, size_t n, rt_hit *d_hi
     if (rc != RT_OK) return rc;
     if (!out || (n && (!d_rays || !d_hits))) return fail(RT_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> g(db->render_lock);
-    HIP_TRY(hipMemset(db->counters, 0, 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(db->counters, 0, rt::kCounterWords * sizeof(unsigned long long)));
     for (size_t at = 0; at < n; at += kChunk) {
         uint32_t m = (uint32_t)std::min(kChunk, n - at);
         if ((rc = with_cursor(*db, nullptr, [&](uint32_t *cursor) {
@@ -1695,7 +1695,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     HIP_TRY(events.make(&ev_begin));
     HIP_TRY(events.make(&ev_end));
     HIP_TRY(hipMemsetAsync(d_rgba, 0, (size_t)o->width * o->height * 4 * sizeof(float), st));
-    if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, 32 * sizeof(unsigned long long), st));
+    if (want_counters) HIP_TRY(hipMemsetAsync(db->counters, 0, rt::kCounterWords * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ev_begin, st));
     // the sampler's tables or per-pixel samples belong to the frame's time
     if ((rc = sampler_prepare(F, n_ranks, true, 0, &db->sampler_mem, &db->sampler_bytes, st)) != RT_OK) return rc;
@@ -1866,10 +1866,10 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
             }
 #endif
 #ifdef RT_PROFILE
-            unsigned long long pr[16];
-            HIP_TRY(hipMemcpy(pr, db->counters + 16, sizeof pr, hipMemcpyDeviceToHost));
+            unsigned long long pr[32];
+            HIP_TRY(hipMemcpy(pr, db->counters + 32, sizeof pr, hipMemcpyDeviceToHost));
             fprintf(stderr, "rt355 profile:");
-            for (int k = 0; k < 16; k++) fprintf(stderr, " %llu", pr[k]);
+            for (int k = 0; k < 32; k++) fprintf(stderr, " %llu", pr[k]);
             fprintf(stderr, "\n");
 #endif
         }

@@ -143,7 +143,11 @@ struct Counters {
     // 9 cycles in all, 10 feed turns, 11 rays
     // 12 cycles of a feed turn after the feed returned (reciprocal direction, enclosing media, root box),
     // 13 cycles in Blocks::take, 14 cycles waiting for the new rays' queue entries, 15 cycles parking
-    PROF(unsigned long long p[16];)
+    // 16-21 plain shading batches, 24-29 general ones: +0 batches, +1 cycles until the parked records
+    // are there, +2 until the queue entries are, +3 in shade(), +4 waiting for the tail atomic,
+    // +5 in the producer's tests and the queue stores; 22 cycles saving lane state, 23 how often,
+    // 30 cycles reloading it
+    PROF(unsigned long long p[32];)
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -299,7 +303,7 @@ RT_DEV bool ball_resolve(const SceneDev &S, const BallDev &b, const Ray &ray, fl
     float t_shell = 0.0f;
     if (b.sphere >= 0 && !sphere_pick(t0, t1, kInf, t_shell)) return false;
     // the medium's wish does not depend on the ray's end
-    const LeafPrim lm = S.leaf[b.best[b.medium] & ~kBestRare];
+    const LeafPrim lm = load_const(S.leaf + (b.best[b.medium] & ~kBestRare));
     const float len = length(ray.d);
     const float hit_dist = __uint_as_float(lm.index) * p_log(medium_uniform(ray, lm.prim));
     float t_end[2];
@@ -345,7 +349,7 @@ RT_DEV void pretest(const SceneDev &S, const Ray &ray, float &t_max, uint32_t &c
     uint32_t which = 0;
     const v3 rd = mk(0.0f, 0.0f, 0.0f); // only boxes read the reciprocal direction; these are spheres
     for (uint32_t e = 0; e < S.n_enclosing; e++) {
-        const LeafPrim lp = S.leaf[S.n_tree_prims + e];
+        const LeafPrim lp = load_const(S.leaf + S.n_tree_prims + e);
         float t;
         if (medium_test(S, lp, r, rd, t)) {
             r.t_max = t;
@@ -353,17 +357,20 @@ RT_DEV void pretest(const SceneDev &S, const Ray &ray, float &t_max, uint32_t &c
         }
     }
     code = which;
+    // balls do not overlap: the first that holds the origin is the only one.  Every lane goes
+    // through all of them, so that k and the ball's record stay wave uniform (scalar registers).
+    bool found = false;
     for (uint32_t k = 0; k < S.n_balls; k++) {
         const BallDev &b = S.balls[k];
         const float dx = r.o.x - b.c[0], dy = r.o.y - b.c[1], dz = r.o.z - b.c[2];
-        if (!(dx * dx + dy * dy + dz * dz < b.r_in2)) continue;
+        if (found || !(dx * dx + dy * dy + dz * dz < b.r_in2)) continue;
+        found = true;
         float t;
         uint32_t won;
         if (ball_resolve(S, b, r, t, won)) {
             r.t_max = t;
             code |= (1u + 3u * k + won) << 8;
         }
-        break; // balls do not overlap: the first that holds the origin is the only one
     }
     t_max = r.t_max;
 }
@@ -508,7 +515,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                         L.best = RT_MISS;
                         for (uint32_t e = 0; e < S.n_enclosing; e++) {
                             const uint32_t slot = S.n_tree_prims + e;
-                            const LeafPrim lp = S.leaf[slot];
+                            const LeafPrim lp = load_const(S.leaf + slot);
                             if (COUNT) cnt.prims[RT_MEDIUM]++;
                             float t;
                             if (medium_test(S, lp, L.ray, inv, t)) {
@@ -519,10 +526,12 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                             }
                         }
                         if constexpr (!ANY) {
+                            bool found = false; // the first ball that holds the origin is the only one
                             for (uint32_t k = 0; k < S.n_balls; k++) {
                                 const BallDev &b = S.balls[k];
                                 const float dx = L.ray.o.x - b.c[0], dy = L.ray.o.y - b.c[1], dz = L.ray.o.z - b.c[2];
-                                if (!(dx * dx + dy * dy + dz * dz < b.r_in2)) continue;
+                                if (found || !(dx * dx + dy * dy + dz * dz < b.r_in2)) continue;
+                                found = true;
                                 float t;
                                 uint32_t won;
                                 if (ball_resolve(S, b, L.ray, t, won)) {
@@ -534,7 +543,6 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                                     if (COUNT) count_resolved(S, (1u + 3u * k + won) << 8, cnt);
                                     occluded = true; // resolved: skip the tree
                                 }
-                                break;
                             }
                         }
                     }
@@ -723,12 +731,12 @@ RT_DEV void flush_counters(const Counters &c, unsigned long long *out) {
         for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[k], (unsigned long long)x);
     }
-    PROF(for (int k = 0; k < 16; k++) {
+    PROF(for (int k = 0; k < 32; k++) {
         unsigned long long x = c.p[k];
         const bool per_lane = k == 1 || k == 4 || k == 11;
         if (per_lane)
             for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[16 + k], x);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[32 + k], x);
     })
 }
 
@@ -1598,17 +1606,21 @@ struct BounceFeed {
     float *dump = nullptr; // where prefetches land (LDS)
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     PROF(unsigned long long prof_take = 0; unsigned long long prof_load = 0; unsigned long long prof_park = 0;)
+    PROF(unsigned long long prof_b[16] = {};)
     RT_DEV bool more() const { return blocks.more(); }
 
-    RT_DEV void compact(bool alive, const Lane &P, uint32_t local, v3 beta, const Rng &rng, uint32_t gpath) {
+    RT_DEV void compact(bool alive, const Lane &P, uint32_t local, v3 beta, const Rng &rng, uint32_t gpath, int prof_at = 0) {
         // stream compaction: ballot, rank by prefix count, one atomic per wave on the tail
         const uint64_t mask = __ballot(alive);
         const uint32_t total = (uint32_t)__popcll(mask);
         if (total) {
+            PROF(const unsigned long long c0 = __builtin_amdgcn_s_memtime();)
             uint32_t base = 0;
             if ((threadIdx.x & 63) == 0) base = atomicAdd(tail, total);
             base = __builtin_amdgcn_readfirstlane(base);
+            PROF(const unsigned long long c1 = __builtin_amdgcn_s_memtime(); prof_b[prof_at + 4] += c1 - c0;)
             if (alive) queue_push(S, qout, out_base + base + lane_rank(mask), P.ray, local, beta, rng, gpath);
+            PROF(prof_b[prof_at + 5] += __builtin_amdgcn_s_memtime() - c1;)
         }
     }
     RT_DEV void compact_shadow(const Shadow &sh, float time, uint32_t local) {
@@ -1638,12 +1650,15 @@ struct BounceFeed {
         Shadow sh;
         sh.want = sh.sampled = false;
         sh.o = sh.d = sh.contrib = mk(0.0f, 0.0f, 0.0f);
+        PROF(const int pa = PLAIN ? 0 : 8; prof_b[pa]++; const unsigned long long s0 = __builtin_amdgcn_s_memtime();)
         if (lane < count) {
             const float4 ra = park_a[first + lane];
             const float2 rb = park_b[first + lane];
+            PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long s1 = __builtin_amdgcn_s_memtime(); prof_b[pa + 1] += s1 - s0;)
             const size_t e = in_base + __float_as_uint(ra.x);
             const float4 qa = qin.a[e], qb = qin.b[e], qc = qin.c[e];
             const uint2 qd = qin.d[e];
+            PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long s2 = __builtin_amdgcn_s_memtime(); prof_b[pa + 2] += s2 - s1;)
             P.ray.o = mk(qa.x, qa.y, qa.z);
             P.ray.time = qa.w;
             P.ray.d = mk(qb.x, qb.y, qb.z);
@@ -1679,9 +1694,10 @@ struct BounceFeed {
             } else {
                 alive = shade<PLAIN>(S, P, beta, rng, local, radiance) && !last;
             }
+            PROF(prof_b[pa + 3] += __builtin_amdgcn_s_memtime() - s2;)
         }
         if (NEE) compact_shadow(sh, P.ray.time, local);
-        compact(alive, P, NEE && sh.sampled ? (local | 0x80000000u) : local, beta, rng, gpath);
+        compact(alive, P, NEE && sh.sampled ? (local | 0x80000000u) : local, beta, rng, gpath PROF(, pa));
     }
 
     RT_DEV bool turn(Trav &T, bool free) {
@@ -1706,6 +1722,7 @@ struct BounceFeed {
             // nothing to keep: free lanes are reloaded or cleared below.
             const bool any_busy = __ballot(T.cur != kNone) != 0;
             uint32_t *sv = save + lane;
+            PROF(const unsigned long long v0 = __builtin_amdgcn_s_memtime();)
             if (any_busy) {
                 sv[0 * 64] = __float_as_uint(L.ray.o.x); sv[1 * 64] = __float_as_uint(L.ray.o.y);
                 sv[2 * 64] = __float_as_uint(L.ray.o.z); sv[3 * 64] = __float_as_uint(L.ray.d.x);
@@ -1721,6 +1738,7 @@ struct BounceFeed {
             // and records parked by other lanes are read below
             asm volatile("" ::: "memory");
             __threadfence_block();
+            PROF(prof_b[6] += __builtin_amdgcn_s_memtime() - v0; prof_b[7]++;)
             if (parked[0] >= 64) {
                 parked[0] -= 64;
                 shade_batch<true>(parked[0], 64);
@@ -1730,6 +1748,7 @@ struct BounceFeed {
                 shade_batch<false>(kParkSlots + parked[1], 64);
             }
             asm volatile("" ::: "memory");
+            PROF(const unsigned long long v1 = __builtin_amdgcn_s_memtime();)
             if (any_busy) {
                 L.ray.o = mk(__uint_as_float(sv[0 * 64]), __uint_as_float(sv[1 * 64]), __uint_as_float(sv[2 * 64]));
                 L.ray.d = mk(__uint_as_float(sv[3 * 64]), __uint_as_float(sv[4 * 64]), __uint_as_float(sv[5 * 64]));
@@ -1743,6 +1762,7 @@ struct BounceFeed {
                 T.cur = sv[15 * 64];
                 T.sp = sv[16 * 64];
                 entry = sv[17 * 64];
+                PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); prof_b[14] += __builtin_amdgcn_s_memtime() - v1;)
             } else {
                 L.ray.o = L.ray.d = T.inv = mk(0.0f, 0.0f, 0.0f);
                 L.ray.t_max = L.ray.time = L.a0 = L.a1 = L.a2 = 0.0f;
@@ -1846,7 +1866,8 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
-    PROF(cnt.p[7] = feed.prof_shade; cnt.p[13] = feed.prof_take; cnt.p[14] = feed.prof_load; cnt.p[15] = feed.prof_park;)
+    PROF(cnt.p[7] = feed.prof_shade; cnt.p[13] = feed.prof_take; cnt.p[14] = feed.prof_load; cnt.p[15] = feed.prof_park;
+         for (int k = 0; k < 16; k++) cnt.p[16 + k] = feed.prof_b[k];)
     if (COUNT) flush_counters(cnt, counters);
 }
 

@@ -108,6 +108,8 @@ constexpr uint32_t kGlobalWaves = RT_GLOBAL_WAVES;
 constexpr uint32_t kMaxEnclosing = 4;
 // Stack entries a lane can keep in a private array beyond its LDS levels.
 constexpr uint32_t kSpillLevels = 56;
+// 64-bit words of a scene's counter block: traversal counters 0-8, tail probe 28-31, profile builds 32-63
+constexpr uint32_t kCounterWords = 64;
 // Dynamic LDS of a trace workgroup (interior records for the LDS-resident shape + stacks).
 size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds);
 
