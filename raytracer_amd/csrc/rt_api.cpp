@@ -95,6 +95,8 @@ struct DeviceBuffers {
     std::mutex render_lock;
     uint32_t ws_paths = 0, ws_depth = 0;
     rt::Queue q[2]{};
+    rt::HitQueue hits{}; // two-kernel bounces only (split_bounces)
+    bool split_bounces = false; // a per-bounce launch is trace + shade (trees in global memory)
     float4 *radiance = nullptr;
     uint32_t *counts = nullptr;
     std::vector<void *> ws_allocs;
@@ -125,6 +127,7 @@ struct DeviceBuffers {
     //   RT355_LOOP_STEAL=0          its waves read their own sub-queue only
     //   RT355_LOOP_TURN_LIMIT=<n>   its spin guard
     //   RT355_TAIL_FILE=<path>      where a probe build writes its per-wave records
+    //   RT355_SPLIT=<0|1>           per-bounce launches fused (0) or as trace + shade kernels (1)
     struct Hooks {
         uint32_t loop_from = 0xffffffffu;
         bool loop_below_set = false;
@@ -132,7 +135,9 @@ struct DeviceBuffers {
         bool loop_steal = true;
         uint32_t turn_limit = rt::kLoopTurnLimit;
         std::string tail_file;
+        int split = -1; // RT355_SPLIT=0/1: a bounce as one fused kernel / as trace + shade kernels (unset: by node source)
         void read() {
+            if (const char *e = getenv("RT355_SPLIT")) split = atoi(e) != 0;
             if (const char *e = getenv("RT355_LOOP_FROM")) {
                 loop_from = (uint32_t)atoi(e);
                 loop_below_set = true;
@@ -936,6 +941,9 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     D.stack_lds = stack_lds;
     db.shape.slots = slots;
     db.shape.lds_nodes = lds_nodes;
+    // trees in global memory: a bounce is a trace launch and a shade launch (measured on the 11 M
+    // primitive scene: +8 %); trees in LDS: one fused launch
+    db.split_bounces = db.hooks.split >= 0 ? db.hooks.split != 0 : !lds_nodes;
     // The bounce kernel binds wave w to sub-queue w % kShards: the wave count of the grid
     // (16 waves per 1024-thread workgroup, 4 per 256-thread one) is kept a multiple of kShards.
     if (lds_nodes) {
@@ -1011,6 +1019,11 @@ int grow_workspace(DeviceBuffers &db, uint32_t paths, uint32_t depth) {
         db.q[k].e = nullptr;
         if ((db.dev.n_enclosing || db.dev.n_balls) && (rc = take(entries * sizeof(uint2), (void **)&db.q[k].e))) return rc;
         db.q[k].cap = cap;
+    }
+    db.hits = rt::HitQueue{};
+    if (db.split_bounces) {
+        if ((rc = take(entries * sizeof(float4), (void **)&db.hits.a))) return rc;
+        if ((rc = take(entries * sizeof(float), (void **)&db.hits.b))) return rc;
     }
     if ((rc = take((size_t)paths * sizeof(float4), (void **)&db.radiance))) return rc;
     if ((rc = take(count_words(depth) * sizeof(uint32_t), (void **)&db.counts))) return rc;
@@ -1634,7 +1647,8 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t per_path = 2 * (3 * sizeof(float4) + sizeof(uint2) + (db->dev.n_enclosing || db->dev.n_balls ? sizeof(uint2) : 0)) +
-                                    sizeof(float4) + ((o->flags & RT_RENDER_DIRECT_LIGHT) ? 3 * sizeof(float4) : 0);
+                                    sizeof(float4) + ((o->flags & RT_RENDER_DIRECT_LIGHT) ? 3 * sizeof(float4) : 0) +
+                                    (db->split_bounces ? sizeof(float4) + sizeof(float) : 0);
             const size_t held = (size_t)db->ws_paths * per_path;
             const size_t fit = (free_b + held) / 2 / per_path;
             if (fit < max_paths) max_paths = (uint32_t)std::max<size_t>(fit, 1u << 16);
@@ -1741,7 +1755,13 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
                 HIP_TRY(rt::launch_bounce_loop(db->dev, db->shape, db->q[b & 1], db->counts, b, o->max_depth - 1,
                                                o->seed, db->radiance, db->bounce_scratch,
                                                want_counters ? db->counters : nullptr, st, loop_steal, turn_limit));
-            else
+            else if (db->split_bounces) {
+                HIP_TRY(rt::launch_trace(db->dev, db->shape, db->q[b & 1], db->hits, db->counts, b,
+                                         want_counters ? db->counters : nullptr, st));
+                HIP_TRY(rt::launch_shade(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1], db->hits, db->counts, b,
+                                         o->max_depth - 1, o->seed, db->radiance, st,
+                                         direct ? &db->shadow : nullptr, db->shadow_counts));
+            } else
                 HIP_TRY(rt::launch_bounce(db->dev, db->shape, db->q[b & 1], db->q[(b + 1) & 1],
                                           db->counts, b, o->max_depth - 1, o->seed, db->radiance,
                                           db->bounce_scratch, want_counters ? db->counters : nullptr, st,

@@ -1871,6 +1871,170 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     if (COUNT) flush_counters(cnt, counters);
 }
 
+// ---- one bounce as two kernels ------------------------------------------------------------------------
+// The fused kernel above shades inside the traversal's register budget and parks, saves and
+// reloads around every batch.  That pays while the tree sits in LDS (one workgroup per CU either
+// way).  A tree in global memory wants as many waves as it can get to hide its fetches, and then
+// the shader's registers are spilled ones: there the bounce is two launches.  This feed only
+// traces: a finished ray leaves its hit beside its queue entry and the lane is refilled.
+struct TraceFeed {
+    static constexpr bool kPretested = true;
+    const SceneDev &S;
+    const Queue &qin;
+    HitQueue hits;
+    size_t in_base;
+    Blocks blocks;
+    uint32_t entry;
+    uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
+    RT_DEV bool more() const { return blocks.more(); }
+    RT_DEV bool turn(Trav &T, bool free) {
+        Lane &L = T.L;
+        if (free && L.has_ray) {
+            hits.a[in_base + entry] = make_float4(__uint_as_float(L.best), L.ray.t_max, L.a0, L.a1);
+            hits.b[in_base + entry] = L.a2;
+        }
+        const uint32_t next = blocks.take(free);
+        bool fresh = false;
+        if (free) {
+            L.has_ray = false;
+            if (next != kNone) {
+                const float4 qa = qin.a[in_base + next], qb = qin.b[in_base + next];
+                uint2 qe = make_uint2(__float_as_uint(kInf), 0u);
+                if (S.n_enclosing | S.n_balls) qe = qin.e[in_base + next];
+                if (__float_as_uint(qb.w) != kDead) {
+                    L.ray.o = mk(qa.x, qa.y, qa.z);
+                    L.ray.time = qa.w;
+                    L.ray.d = mk(qb.x, qb.y, qb.z);
+                    L.ray.t_max = __uint_as_float(qe.x);
+                    bool resolved;
+                    L.best = pretest_best(S, qe.y, resolved);
+                    code = qe.y;
+                    L.a0 = L.a1 = L.a2 = 0.0f;
+                    entry = next;
+                    L.has_ray = true;
+                    fresh = true;
+                }
+            }
+        }
+        return fresh;
+    }
+    RT_DEV bool drain() { return false; }
+    RT_DEV void finish() {}
+};
+
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_trace(
+    SceneDev S, Queue qin, HitQueue hits, uint32_t *counts, uint32_t bounce, unsigned long long *counters) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
+    const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
+    uint32_t longest = my_count;
+    for (int s = 32; s > 0; s >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, s, 64));
+    const uint32_t n_chunks = kShards * ((longest + 63) / 64);
+    if (blockIdx.x * (blockDim.x >> 6) >= n_chunks) return; // nothing for this workgroup (uniform)
+    const TreeView<LDSN> tv = tree_view<LDSN>(S);
+    Counters cnt = {};
+    const uint32_t w = wave_index(), shard = shard_of_wave(w), per_shard = wave_total() / kShards;
+    const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
+    TraceFeed feed{S, qin, hits, (size_t)shard * qin.cap,
+                   Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
+                          counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
+                   0u};
+    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt,
+                                     bounce == 0 ? primary_refill_lanes_of<LDSN>()
+                                                 : (LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL_HIT));
+    if (COUNT) flush_counters(cnt, counters);
+}
+
+// Shades the segments of one bounce from their queue entries and the hits k_trace left, 64
+// consecutive entries per wave and step, and compacts the survivors into the next queue: one
+// ballot, one prefix count and one atomic per wave and step, as BounceFeed::compact does.
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+template <bool NEE>
+__global__ __launch_bounds__(kBlock, RT_SHADE_WAVES) void k_shade(
+    SceneDev S, Queue qin, Queue qout, HitQueue hits, uint32_t *counts, uint32_t bounce, uint32_t last_bounce,
+    uint64_t seed, float4 *radiance, ShadowQueue sq, uint32_t *scounts) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t *cin = counts + (size_t)bounce * kShards * kCountStride;
+    uint32_t *cout = counts + (size_t)(bounce + 1) * kShards * kCountStride;
+    const uint32_t my_count = lane < kShards ? cin[lane * kCountStride] : 0u;
+    const uint32_t w = wave_index(), shard = w % kShards, per_shard = wave_total() / kShards;
+    const uint32_t n = __builtin_amdgcn_readlane(my_count, shard);
+    const size_t in_base = (size_t)shard * qin.cap, out_base = (size_t)shard * qout.cap;
+    uint32_t *tail = cout + shard * kCountStride;
+    uint32_t *stail = NEE ? scounts + ((size_t)bounce * kShards + shard) * kCountStride : nullptr;
+    const size_t shadow_base = (size_t)shard * sq.cap;
+    const bool last = bounce == last_bounce;
+    for (uint32_t blk = (w / kShards) * 64u; blk < n; blk += per_shard * 64u) {
+        bool alive = false;
+        Lane P;
+        P.ray.o = P.ray.d = mk(0.0f, 0.0f, 0.0f);
+        P.ray.t_max = P.ray.time = 0.0f;
+        v3 beta = mk(0.0f, 0.0f, 0.0f);
+        Rng rng{0, 0};
+        uint32_t gpath = 0, local = kDead;
+        Shadow sh;
+        sh.want = sh.sampled = false;
+        sh.o = sh.d = sh.contrib = mk(0.0f, 0.0f, 0.0f);
+        const size_t e = in_base + blk + lane;
+        float4 qb = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kDead));
+        if (blk + lane < n) qb = qin.b[e];
+        if (__float_as_uint(qb.w) != kDead) {
+            const float4 qa = qin.a[e], qc = qin.c[e], ha = hits.a[e];
+            const uint2 qd = qin.d[e];
+            P.ray.o = mk(qa.x, qa.y, qa.z);
+            P.ray.time = qa.w;
+            P.ray.d = mk(qb.x, qb.y, qb.z);
+            P.ray.t_max = ha.y;
+            P.best = __float_as_uint(ha.x);
+            P.a0 = ha.z;
+            P.a1 = ha.w;
+            P.a2 = hits.b[e];
+            P.has_ray = true;
+            local = __float_as_uint(qb.w);
+            beta = mk(qc.x, qc.y, qc.z);
+            gpath = qd.y;
+            rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
+            rng.inc = (((seed << 32) + gpath) << 1) | 1u;
+            const bool general = P.best != RT_MISS && (P.best & kBestRare) != 0;
+            bool skip_emission = false;
+            if (NEE) { // bit 31 of the path index: the vertex before this one sampled the lights
+                skip_emission = (local >> 31) != 0;
+                local &= 0x7fffffffu;
+            }
+            if (general) alive = shade<false, NEE>(S, P, beta, rng, local, radiance, skip_emission, &sh) && !last;
+            else alive = shade<true, NEE>(S, P, beta, rng, local, radiance, skip_emission, &sh) && !last;
+        }
+        if (NEE) {
+            const uint64_t mask = __ballot(sh.want);
+            const uint32_t total = (uint32_t)__popcll(mask);
+            if (total) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(stail, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (sh.want) {
+                    const size_t slot = shadow_base + base + lane_rank(mask);
+                    sq.a[slot] = make_float4(sh.o.x, sh.o.y, sh.o.z, P.ray.time);
+                    sq.b[slot] = make_float4(sh.d.x, sh.d.y, sh.d.z, __uint_as_float(local));
+                    sq.c[slot] = make_float4(sh.contrib.x, sh.contrib.y, sh.contrib.z, 0.0f);
+                }
+            }
+        }
+        const uint64_t mask = __ballot(alive);
+        const uint32_t total = (uint32_t)__popcll(mask);
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(tail, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (alive)
+                queue_push(S, qout, out_base + base + lane_rank(mask), P.ray,
+                           NEE && sh.sampled ? (local | 0x80000000u) : local, beta, rng, gpath);
+        }
+    }
+}
+
 // ---- shadow rays (direct lighting) ----------------------------------------------------------------------
 // The rays Interaction::spawn_ray_to made during one bounce, through the any-hit traversal
 // (<BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863).  A ray that reaches its
@@ -2588,6 +2752,50 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
         }
     }
 #undef RT_BOUNCE
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const SceneDev &S, const LaunchShape &L, const Queue &qin, const HitQueue &hits,
+                        uint32_t *counts, uint32_t bounce, unsigned long long *counters, hipStream_t stream) {
+    const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
+    const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
+    if (L.lds_nodes) {
+        if (counters) RT_LAUNCH((k_trace<true, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
+        else RT_LAUNCH((k_trace<false, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
+    } else {
+        if (counters) RT_LAUNCH((k_trace<true, false>), L.grid, threads, S, qin, hits, counts, bounce, counters);
+        else RT_LAUNCH((k_trace<false, false>), L.grid, threads, S, qin, hits, counts, bounce, counters);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
+                        const HitQueue &hits, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
+                        float4 *radiance, hipStream_t stream, const ShadowQueue *shadow, uint32_t *shadow_counts) {
+    // every workgroup resident at once (each wave strides over its share of the blocks), and a wave
+    // count that is a multiple of kShards
+    static int per_cu[2] = {0, 0}, cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k_shade<false>, kBlock, 0);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k_shade<true>, kBlock, 0);
+        if (e != hipSuccess) return e;
+        cus = prop.multiProcessorCount;
+    }
+    (void)L;
+    uint32_t blocks = (uint32_t)cus * (uint32_t)(per_cu[shadow ? 1 : 0] > 0 ? per_cu[shadow ? 1 : 0] : 1);
+    blocks = blocks / 8u * 8u;
+    if (blocks == 0) blocks = 8;
+    const ShadowQueue sq = shadow ? *shadow : ShadowQueue{nullptr, nullptr, nullptr, 0u};
+    if (shadow)
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kBlock), 0, stream, S, qin, qout, hits, counts, bounce,
+                           last, seed, radiance, sq, shadow_counts);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kBlock), 0, stream, S, qin, qout, hits, counts, bounce,
+                           last, seed, radiance, sq, shadow_counts);
     return hipGetLastError();
 }
 

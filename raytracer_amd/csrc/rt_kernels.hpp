@@ -42,6 +42,13 @@ struct ShadowQueue {
     uint32_t cap;
 };
 
+// Closest hits of one bounce, entry for entry beside the Queue they were traced from: what the
+// trace kernel of the two-kernel bounce (launch_trace) leaves for the shading kernel (launch_shade).
+struct HitQueue {
+    float4 *a; // leaf slot of the hit (bits; | 0x80000000 if it needs the general shader) or RT_MISS, t, two primitive-specific values
+    float *b;  // the third primitive-specific value
+};
+
 // Halton::new (colour/src/samplers/halton.rs:25-52) for one frame size, plus the digit
 // permutations of the primes 5, 7 and 11 (data/src/lib.rs:16-41) that dimensions 2-4 use.
 struct HaltonDev {
@@ -151,6 +158,17 @@ hipError_t launch_bounce(const SceneDev &S, const LaunchShape &L, const Queue &q
                          uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed, float4 *radiance,
                          uint8_t *scratch, unsigned long long *counters, hipStream_t stream,
                          const ShadowQueue *shadow = nullptr, uint32_t *shadow_counts = nullptr);
+// One bounce as two kernels, for trees that stay in global memory: launch_trace finds the closest hit
+// of every queued segment and writes it to `hits` (the traversal keeps all of its registers and
+// waves), launch_shade reads queue and hits front to back, shades, and compacts the survivors into
+// qout (and the shadow rays into *shadow) exactly as launch_bounce does.  Same images, counters
+// and queue sizes as launch_bounce.
+hipError_t launch_trace(const SceneDev &S, const LaunchShape &L, const Queue &qin, const HitQueue &hits,
+                        uint32_t *counts, uint32_t bounce, unsigned long long *counters, hipStream_t stream);
+hipError_t launch_shade(const SceneDev &S, const LaunchShape &L, const Queue &qin, const Queue &qout,
+                        const HitQueue &hits, uint32_t *counts, uint32_t bounce, uint32_t last, uint64_t seed,
+                        float4 *radiance, hipStream_t stream, const ShadowQueue *shadow = nullptr,
+                        uint32_t *shadow_counts = nullptr);
 // The shadow rays bounce `bounce` made, through the any-hit traversal (BVH::does_intersect,
 // bvh.rs:801-863); an unoccluded ray adds its contribution to its path's radiance.
 hipError_t launch_shadow(const SceneDev &S, const LaunchShape &L, const ShadowQueue &q, uint32_t *shadow_counts,

@@ -233,6 +233,36 @@ def test_streaming_paths(monkeypatch, nodes):
     assert img.tobytes() == ref.tobytes() and st.segments == rst.segments
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("direct", [False, True])
+def test_bounce_as_one_kernel_or_two(monkeypatch, scene_cache, nodes, direct):
+    """A bounce is one fused launch (trees in LDS) or a trace launch and a shade launch (trees in
+    global memory); RT355_SPLIT forces either form on either node source.  Frames, segment counts
+    per bounce and traversal counters must not depend on the form, and equal the oracle's."""
+    from raytracer_amd import abi
+    if nodes == "global":
+        monkeypatch.setenv("RT355_NODES", "global")
+    name, cam, fr = scene_cache("cornell" if direct else "week")
+    flags = abi.RT_RENDER_DIRECT_LIGHT if direct else 0
+    w, h, spp, depth = 96, 64, 5, 12
+    o = orc.OracleScene(fr)
+    ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, depth, seed=4, flags=flags | abi.RT_RENDER_COUNTERS))
+    per_bounce = None
+    for split in (0, 1):
+        # RT355_LOOP_BELOW=0: every bounce is a per-bounce launch, so the form under test runs throughout
+        g = scene_with_hooks(monkeypatch, fr, RT355_SPLIT=split, RT355_LOOP_BELOW=0)
+        img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=4, flags=flags))
+        assert img.tobytes() == ref.tobytes(), (nodes, split)
+        assert st.segments == rst.segments, (nodes, split)
+        assert per_bounce is None or list(st.bounce_rays) == per_bounce
+        per_bounce = list(st.bounce_rays)
+        img2, cst = g.render(cam(w, h), lib.render_opts(w, h, spp, depth, seed=4, flags=flags | abi.RT_RENDER_COUNTERS))
+        assert img2.tobytes() == ref.tobytes()
+        assert cst.nodes_visited == rst.nodes_visited and list(cst.prims_tested) == list(rst.prims_tested), (nodes, split)
+        g.close()
+
+
 def _cam(w, h):
     from raytracer_amd.scene import look_at, perspective_camera
     return perspective_camera(w, h, 40.0, look_at((0.0, 0.0, 2.0), (0.0, 0.0, -3.0), (0.0, 1.0, 0.0)))
