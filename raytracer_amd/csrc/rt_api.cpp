@@ -633,6 +633,89 @@ uint32_t cluster_records(const std::vector<rt_linear_node> &nodes, std::vector<u
     return next;
 }
 
+// Four-box records for trees that are traversed from global memory (SceneDev::quads): one
+// 128-byte record per interior node that the walk reaches in an even number of steps from the
+// root, with the boxes of that node's grandchildren -- or of a child itself where the child is a
+// leaf.  Records are numbered depth first.  A random 128-byte read costs the memory system what a
+// random 64-byte one does, so a ray that walks these records makes half as many dependent fetches.
+// Skipping the children's own box tests is exact only if every interior node's box is the union
+// of its children's boxes, bit for bit (the builders make it so; checked here): returns false
+// otherwise, or when the tree is a single leaf, and the kernels then walk the two-box records.
+// stack_need: the most entries a lane can have stacked (up to three per record on its way down).
+bool build_quads(const std::vector<rt_linear_node> &nodes, std::vector<float4> &out, uint32_t &stack_need) {
+    out.clear();
+    stack_need = 0;
+    if (nodes.empty() || nodes[0].primitive_count) return false;
+    auto leaf = [&](uint32_t i) { return nodes[i].primitive_count != 0; };
+    std::vector<uint32_t> quad_of(nodes.size(), 0xffffffffu), order, todo{0};
+    while (!todo.empty()) {
+        const uint32_t i = todo.back();
+        todo.pop_back();
+        quad_of[i] = (uint32_t)order.size();
+        order.push_back(i);
+        uint32_t next[4], n_next = 0;
+        const uint32_t kids[2] = {i + 1, nodes[i].child_offset};
+        for (uint32_t c : kids) {
+            if (leaf(c)) continue;
+            const uint32_t grand[2] = {c + 1, nodes[c].child_offset};
+            for (uint32_t g : grand)
+                if (!leaf(g)) next[n_next++] = g;
+        }
+        while (n_next) todo.push_back(next[--n_next]); // the first of them is numbered next
+    }
+    if (order.size() >= (1u << 31)) return false;
+    auto bits = [](uint32_t v) {
+        float f;
+        memcpy(&f, &v, 4);
+        return f;
+    };
+    out.assign(8 * order.size(), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    std::vector<uint32_t> need(order.size(), 0);
+    for (size_t r = order.size(); r-- > 0;) { // children's records have larger numbers
+        const uint32_t i = order[r];
+        const uint32_t kids[2] = {i + 1, nodes[i].child_offset};
+        const rt_linear_node *box[4] = {nullptr, nullptr, nullptr, nullptr};
+        uint32_t ref[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint32_t axes = nodes[i].axis & 3u, entries = 0, deepest = 0;
+        for (int side = 0; side < 2; side++) {
+            const uint32_t c = kids[side];
+            if (leaf(c)) {
+                box[2 * side] = &nodes[c];
+                ref[2 * side] = rt::kLeafRef | nodes[c].child_offset;
+                entries++;
+                continue;
+            }
+            const uint32_t grand[2] = {c + 1, nodes[c].child_offset};
+            for (int k = 0; k < 3; k++) { // the child's box must be the union of its children's
+                const float lo = std::min(nodes[grand[0]].lo[k], nodes[grand[1]].lo[k]);
+                const float hi = std::max(nodes[grand[0]].hi[k], nodes[grand[1]].hi[k]);
+                if (!(lo == nodes[c].lo[k] && hi == nodes[c].hi[k])) return false;
+            }
+            axes |= (nodes[c].axis & 3u) << (2 + 2 * side);
+            for (int k = 0; k < 2; k++) {
+                const uint32_t g = grand[k];
+                box[2 * side + k] = &nodes[g];
+                ref[2 * side + k] = leaf(g) ? (rt::kLeafRef | nodes[g].child_offset) : quad_of[g];
+                if (!leaf(g)) deepest = std::max(deepest, need[quad_of[g]]);
+                entries++;
+            }
+        }
+        need[r] = entries - 1 + deepest;
+        float4 *q = out.data() + 8 * r;
+        const float meta[4] = {bits(axes), 0.0f, 0.0f, 0.0f};
+        for (int e = 0; e < 4; e++) {
+            const rt_linear_node *b = box[e];
+            // references ride in the first four quarters, the axes in the fifth
+            q[2 * e] = make_float4(b ? b->lo[0] : 0.0f, b ? b->lo[1] : 0.0f, b ? b->lo[2] : 0.0f, 0.0f);
+            q[2 * e + 1] = make_float4(b ? b->hi[0] : 0.0f, b ? b->hi[1] : 0.0f, b ? b->hi[2] : 0.0f, 0.0f);
+        }
+        for (int e = 0; e < 4; e++) q[e].w = bits(ref[e]);
+        q[4].w = meta[0];
+    }
+    stack_need = need[0];
+    return true;
+}
+
 // Lays the scene out for the kernels: one 64-byte record per interior node with
 // the boxes of both children, the primitive list in leaf order, and every typed
 // table re-packed in the order the leaves reference it so that a leaf's
@@ -828,6 +911,16 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     rt::SceneDev &D = db.dev;
     int rc;
     if ((rc = upload(db, dn, &D.nodes))) return rc;
+    // four-box records beside them for trees in global memory (RT355_QUADS=0: not, a test hook)
+    std::vector<float4> dq;
+    uint32_t quad_need = 0;
+    const char *quads_hook = getenv("RT355_QUADS");
+    bool quads = !lds_nodes && !(quads_hook && atoi(quads_hook) == 0) && build_quads(nodes, dq, quad_need);
+    if (quads && quad_need > rt::kSpillLevels) quads = false; // deeper than a lane's stack: two-box records only
+    D.quads = nullptr;
+    D.root_quad = 0;
+    if (quads && (rc = upload(db, dq, &D.quads))) return rc;
+    dq = std::vector<float4>();
     if ((rc = upload(db, leaf, &D.leaf))) return rc;
     if ((rc = upload(db, plain, &D.plain))) return rc;
     if ((rc = upload(db, spheres, &D.spheres))) return rc;
@@ -941,6 +1034,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     D.stack_lds = stack_lds;
     db.shape.slots = slots;
     db.shape.lds_nodes = lds_nodes;
+    db.shape.quads = quads;
     // trees in global memory: a bounce is a trace launch and a shade launch (measured on the 11 M
     // primitive scene: +8 %); trees in LDS: one fused launch
     db.split_bounces = db.hooks.split >= 0 ? db.hooks.split != 0 : !lds_nodes;

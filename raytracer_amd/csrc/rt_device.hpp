@@ -103,6 +103,16 @@ struct SceneDev {
     //   {lo0.xyz, ref0} {hi0.xyz, ref1} {lo1.xyz, split axis} {hi1.xyz, -}
     // refN = index of the child's own record, or kLeafRef | first primitive of a leaf child.
     const float4 *nodes;
+    // Trees in global memory also come as one 128-byte record per interior node at an even level
+    // below the root, holding the boxes of its (up to four) grandchildren:
+    //   {lo.xyz of entry 0, ref 0} {hi 0, ref 1} {lo 1, ref 2} {hi 1, ref 3} {lo 2, axes} {hi 2, -} {lo 3, -} {hi 3, -}
+    // entries 0, 1 = the children of the node's first child, 2, 3 = those of its second child; a
+    // child that is a leaf stands as the first entry of its side and the second is empty (ref
+    // 0xFFFFFFFF).  ref = index of the entry's own record here, or kLeafRef | first primitive.
+    // axes: bits 0-1 the node's split axis, 2-3 its first child's, 4-5 its second child's.
+    // Null when the tree is in LDS or has no such records.
+    const float4 *quads;
+    uint32_t root_quad; // reference to the root in `quads` terms
     const LeafPrim *leaf;     // n_prims
     const float4 *spheres;    // {c.xyz, r}
     const MSphere *msph;

@@ -427,9 +427,22 @@ RT_DEV void count_resolved(const SceneDev &S, uint32_t code, Counters &cnt) {
 // received a ray (it may save the whole of Trav to memory and reload it), and
 // bool drain(), called when nothing is left to hand out: true if the feed found more after
 // all (only a feed that turns results into new rays), and void finish(), called once at the end.
-template <bool ANY, bool COUNT, bool LDSN, class Feed>
+//
+// WIDE (trees in global memory, no counters): an interior step reads a 128-byte record with the boxes
+// of a node's four grandchildren (SceneDev::quads) and so goes down two levels of the tree.  The
+// memory system delivers a random 128-byte record as fast as a random 64-byte one, so half as many
+// dependent fetches walk the same tree.  The children's own boxes are not tested: a grandchild's
+// box lies inside its parent's, every term of the box test is monotone in the box, and a ray only
+// gets shorter, so a grandchild that passes its test when it is due implies that its parent passed
+// when it was -- provided no term is NaN.  NaN needs 0 x infinity, i.e. a direction component that
+// is zero (infinite reciprocal), or a non-finite origin or reciprocal; such rays (`exact`) walk the
+// two-box records instead, in the same loop.  The four entries are visited in the order the
+// reference would reach them: the near child's side first (split axis of the node), within a side
+// the near grandchild first (split axis of the child).
+template <bool ANY, bool COUNT, bool LDSN, bool WIDE, class Feed>
 RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed, Counters &cnt,
                          const uint32_t refill_lanes = refill_lanes_of<LDSN>()) {
+    static_assert(!WIDE || (!LDSN && !COUNT), "four-box records: global memory, no counters");
     constexpr int kStride = Shape<LDSN>::kThreads;
     constexpr uint32_t leaf_lanes = LDSN ? kLeafLanes : (uint32_t)RT_LEAF_LANES_GLOBAL;
     using RefT = typename Shape<LDSN>::RefT;
@@ -449,6 +462,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
     L.ray.t_max = L.ray.time = 0.0f;
     inv = mk(0.0f, 0.0f, 0.0f);
     bool negx = false, negy = false, negz = false;
+    bool exact = false; // WIDE: this lane's ray walks the two-box records
     sp = 0;
     cur = kNone;
 
@@ -551,7 +565,14 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                         float t;
                         float4 r0 = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.0f);
                         float4 r1 = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.0f);
-                        if (slab(r0, r1, L.ray, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f, t)) cur = S.root_ref;
+                        if constexpr (WIDE) {
+                            auto plain = [](float v) { return fabsf(v) < kInf && v != 0.0f; }; // false for NaN too
+                            auto finite = [](float v) { return fabsf(v) < kInf; };
+                            exact = !(plain(inv.x) && plain(inv.y) && plain(inv.z) && finite(L.ray.o.x) &&
+                                      finite(L.ray.o.y) && finite(L.ray.o.z));
+                        }
+                        if (slab(r0, r1, L.ray, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f, t))
+                            cur = (WIDE && !exact) ? S.root_quad : S.root_ref;
                     }
                     PROF(if (COUNT) cnt.p[11]++;)
                 }
@@ -584,7 +605,45 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             if (n_hold >= leaf_lanes) break;
             if (can_refill && 64u - n_step - n_hold >= refill_lanes) break;
             PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
-            if (stepping) {
+            if (WIDE && stepping && !exact) {
+                const float4 *q = S.quads + 8 * (size_t)cur;
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+                // entries 0, 1: the first child's children (or the child itself, a leaf, and nothing);
+                // entries 2, 3: the second child's
+                const uint32_t e0 = __float_as_uint(q0.w), e1 = __float_as_uint(q1.w), e2 = __float_as_uint(q2.w),
+                               e3 = __float_as_uint(q3.w), meta = __float_as_uint(q4.w);
+                float t0, t1, t2, t3;
+                const bool h0 = slab(q0, q1, L.ray, inv, negx, negy, negz, t0);
+                const bool h1 = slab(q2, q3, L.ray, inv, negx, negy, negz, t1) && e1 != kNone;
+                const bool h2 = slab(q4, q5, L.ray, inv, negx, negy, negz, t2);
+                const bool h3 = slab(q6, q7, L.ray, inv, negx, negy, negz, t3) && e3 != kNone;
+                auto neg_of = [&](uint32_t axis) { return axis == 0 ? negx : (axis == 1 ? negy : negz); };
+                const bool second_side = neg_of(meta & 3u);      // the node's second child is nearer
+                const bool swap_a = neg_of((meta >> 2) & 3u);    // the first child's second child is nearer
+                const bool swap_b = neg_of((meta >> 4) & 3u);
+                // the sides in their own visiting order
+                const uint32_t a0r = swap_a ? e1 : e0, a1r = swap_a ? e0 : e1;
+                const float a0t = swap_a ? t1 : t0, a1t = swap_a ? t0 : t1;
+                const bool a0h = swap_a ? h1 : h0, a1h = swap_a ? h0 : h1;
+                const uint32_t b0r = swap_b ? e3 : e2, b1r = swap_b ? e2 : e3;
+                const float b0t = swap_b ? t3 : t2, b1t = swap_b ? t2 : t3;
+                const bool b0h = swap_b ? h3 : h2, b1h = swap_b ? h2 : h3;
+                // all four, last to first: whatever comes later in the visiting order waits on the stack
+                uint32_t cand = kNone;
+                float cand_t = 0.0f;
+                auto offer = [&](bool h, uint32_t r, float t) {
+                    if (h) {
+                        if (cand != kNone) push(cand, cand_t);
+                        cand = r;
+                        cand_t = t;
+                    }
+                };
+                offer(second_side ? a1h : b1h, second_side ? a1r : b1r, second_side ? a1t : b1t);
+                offer(second_side ? a0h : b0h, second_side ? a0r : b0r, second_side ? a0t : b0t);
+                offer(second_side ? b1h : a1h, second_side ? b1r : a1r, second_side ? b1t : a1t);
+                offer(second_side ? b0h : a0h, second_side ? b0r : a0r, second_side ? b0t : a0t);
+                cur = cand != kNone ? cand : pop();
+            } else if (stepping) {
                 bool need_pop = true;
                 {
                     float4 q0, q1, q2, q3;
@@ -799,13 +858,13 @@ RT_DEV Blocks flat_blocks(uint32_t n, uint32_t *cursors, bool mix_slots) {
     return b;
 }
 
-template <bool COUNT, bool LDSN>
+template <bool COUNT, bool LDSN, bool WIDE = false>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_intersect(
     SceneDev S, const rt_ray *rays, uint32_t n, rt_hit *hits, unsigned long long *counters, uint32_t *cursor) {
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
     HitFeed feed{S, rays, hits, flat_blocks(n, cursor, LDSN), kNone};
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL_HIT);
+    trace_stream<false, COUNT, LDSN, WIDE>(S, tv, feed, cnt, LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL_HIT);
     if (COUNT) flush_counters(cnt, counters);
 }
 
@@ -833,13 +892,13 @@ struct AnyFeed {
 };
 
 // <BVH as Primitive>::does_intersect, shapes/src/bvh.rs:801-863
-template <bool LDSN>
+template <bool LDSN, bool WIDE = false>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_occluded(
     SceneDev S, const rt_ray *rays, uint32_t n, uint8_t *out, uint32_t *cursor) {
     const TreeView<LDSN> tv = tree_view<LDSN>(S);
     Counters cnt = {};
     AnyFeed feed{rays, out, flat_blocks(n, cursor, LDSN), kNone};
-    trace_stream<true, false, LDSN>(S, tv, feed, cnt);
+    trace_stream<true, false, LDSN, WIDE>(S, tv, feed, cnt);
 }
 
 // ---- camera, colour/src/camera/perspective.rs:54-78 -----------------------------------------
@@ -1865,7 +1924,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     feed.dump = tv.dump;
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
+    trace_stream<false, COUNT, LDSN, false>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
     PROF(cnt.p[7] = feed.prof_shade; cnt.p[13] = feed.prof_take; cnt.p[14] = feed.prof_load; cnt.p[15] = feed.prof_park;
          for (int k = 0; k < 16; k++) cnt.p[16 + k] = feed.prof_b[k];)
     if (COUNT) flush_counters(cnt, counters);
@@ -1922,7 +1981,7 @@ struct TraceFeed {
     RT_DEV void finish() {}
 };
 
-template <bool COUNT, bool LDSN>
+template <bool COUNT, bool LDSN, bool WIDE = false>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_trace(
     SceneDev S, Queue qin, HitQueue hits, uint32_t *counts, uint32_t bounce, unsigned long long *counters) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1940,7 +1999,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                    Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
                           counts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
                    0u};
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt,
+    trace_stream<false, COUNT, LDSN, WIDE>(S, tv, feed, cnt,
                                      bounce == 0 ? primary_refill_lanes_of<LDSN>()
                                                  : (LDSN ? kRefillLanes : (uint32_t)RT_REFILL_LANES_GLOBAL_HIT));
     if (COUNT) flush_counters(cnt, counters);
@@ -2074,7 +2133,7 @@ struct ShadowFeed {
     RT_DEV void finish() {}
 };
 
-template <bool LDSN>
+template <bool LDSN, bool WIDE = false>
 __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_shadow(
     SceneDev S, ShadowQueue q, uint32_t *scounts, uint32_t bounce, float4 *radiance) {
     const uint32_t lane = threadIdx.x & 63;
@@ -2092,7 +2151,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                     Blocks{(w / kShards) * 64, 0u, n, per_shard * 64,
                            scounts + ((size_t)bounce * kShards + shard) * kCountStride + 1, per_shard, 1u, 0u},
                     radiance, kNone};
-    trace_stream<true, false, LDSN>(S, tv, feed, cnt);
+    trace_stream<true, false, LDSN, WIDE>(S, tv, feed, cnt);
 }
 
 // ---- the rest of the path in one launch ------------------------------------------------------------
@@ -2465,7 +2524,7 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
     if (COUNT) feed.cnt = &cnt;
     feed.dump = tv.dump;
     feed.blocks.start();
-    trace_stream<false, COUNT, LDSN>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
+    trace_stream<false, COUNT, LDSN, false>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
 #ifdef RT_TAIL_PROBE
     // when do the waves of a launch finish?  (100 MHz clock; slots 28-31 of the counters)
@@ -2624,6 +2683,7 @@ hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ra
         else RT_LAUNCH((k_intersect<false, true>), blocks, threads, S, rays, n, hits, counters, cursor);
     } else {
         if (counters) RT_LAUNCH((k_intersect<true, false>), blocks, threads, S, rays, n, hits, counters, cursor);
+        else if (L.quads) RT_LAUNCH((k_intersect<false, false, true>), blocks, threads, S, rays, n, hits, counters, cursor);
         else RT_LAUNCH((k_intersect<false, false>), blocks, threads, S, rays, n, hits, counters, cursor);
     }
     return hipGetLastError();
@@ -2637,6 +2697,7 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
     if (blocks == 0) return hipSuccess;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out, cursor);
+    else if (L.quads) RT_LAUNCH((k_occluded<false, true>), blocks, threads, S, rays, n, out, cursor);
     else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out, cursor);
     return hipGetLastError();
 }
@@ -2706,8 +2767,14 @@ hipError_t launch_generate(const SceneDev &S, const FrameDev &F, const rt_camera
 }
 
 hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu) {
-    int n[4] = {0, 0, 0, 0};
+    int n[7] = {0, 0, 0, 0, 0, 0, 0};
     hipError_t e = allow_lds(k_bounce<false, false, false>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_trace<false, false, true>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_intersect<false, false, true>, lds_bytes);
+    if (e == hipSuccess) e = allow_lds(k_occluded<false, true>, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[4], k_trace<false, false, true>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[5], k_intersect<false, false, true>, kBlock, lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[6], k_occluded<false, true>, kBlock, lds_bytes);
     if (e == hipSuccess) e = allow_lds(k_bounce<true, false, false>, lds_bytes);
     if (e == hipSuccess) e = allow_lds(k_intersect<false, false>, lds_bytes);
     if (e == hipSuccess) e = allow_lds(k_occluded<false>, lds_bytes);
@@ -2717,7 +2784,7 @@ hipError_t resident_workgroups(size_t lds_bytes, uint32_t *per_cu) {
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], k_occluded<false>, kBlock, lds_bytes);
     if (e != hipSuccess) return e;
     int m = n[0];
-    for (int k = 1; k < 4; k++) m = n[k] < m ? n[k] : m;
+    for (int k = 1; k < 7; k++) m = n[k] < m ? n[k] : m;
     *per_cu = m > 0 ? (uint32_t)m : 1u;
     return hipSuccess;
 }
@@ -2764,6 +2831,7 @@ hipError_t launch_trace(const SceneDev &S, const LaunchShape &L, const Queue &qi
         else RT_LAUNCH((k_trace<false, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
     } else {
         if (counters) RT_LAUNCH((k_trace<true, false>), L.grid, threads, S, qin, hits, counts, bounce, counters);
+        else if (L.quads) RT_LAUNCH((k_trace<false, false, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
         else RT_LAUNCH((k_trace<false, false>), L.grid, threads, S, qin, hits, counts, bounce, counters);
     }
     return hipGetLastError();
@@ -2804,6 +2872,7 @@ hipError_t launch_shadow(const SceneDev &S, const LaunchShape &L, const ShadowQu
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) RT_LAUNCH((k_shadow<true>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
+    else if (L.quads) RT_LAUNCH((k_shadow<false, true>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
     else RT_LAUNCH((k_shadow<false>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
     return hipGetLastError();
 }

@@ -102,6 +102,7 @@ struct LaunchShape {
     uint32_t slots;  // traversal stack entries a lane can need
     uint32_t grid;   // persistent workgroups
     bool lds_nodes;  // node array staged in LDS (1024-thread workgroups), else 256-thread workgroups
+    bool quads;      // trees in global memory: SceneDev::quads holds the four-box records the kernels without counters walk
 };
 
 // Resident 256-thread workgroups per CU (= waves per SIMD) the kernels that read the tree

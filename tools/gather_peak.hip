@@ -64,6 +64,21 @@ __global__ __launch_bounds__(256, WAVES) void k_chain(const uint4 *table, uint32
     out[tid] = acc;
 }
 
+// the same chain over 128-byte records (two adjacent 64-byte lines per step, eight 16-byte loads):
+// what a step costs when a record holds four child boxes instead of two
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_chain128(const uint4 *table, uint32_t n_records, uint32_t iters, uint32_t *out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t idx = mix(tid) % n_records, acc = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint4 *p = table + 8 * (size_t)idx;
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
+        acc += b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ h.w;
+        idx = (a.x + (acc & 1u)) % n_records;
+    }
+    out[tid] = acc;
+}
+
 template <class K>
 static double time_ms(K launch) {
     hipEvent_t e0, e1;
@@ -114,6 +129,17 @@ int main() {
             const double recs = (double)blocks * 256 * iters;
             printf("{\"table_MB\": %u, \"shape\": \"dependent chain, 8 waves/SIMD\", \"Grecords_per_s\": %.2f, \"GB_per_s\": %.1f}\n", mb,
                    recs / ms / 1e6, recs * 64 / ms / 1e6);
+        }
+        for (int waves : {4, 6}) {
+            const uint32_t iters = 256, blocks = cus * waves, n128 = n_records / 2;
+            // first words were drawn below n_records: fold them into the half as many 128-byte records
+            const double ms = time_ms([&] {
+                if (waves == 4) hipLaunchKernelGGL(k_chain128<4>, dim3(blocks), dim3(256), 0, 0, table, n128, iters, out);
+                else hipLaunchKernelGGL(k_chain128<6>, dim3(blocks), dim3(256), 0, 0, table, n128, iters, out);
+            });
+            const double recs = (double)blocks * 256 * iters;
+            printf("{\"table_MB\": %u, \"shape\": \"dependent chain of 128-byte records, %d waves/SIMD\", \"Grecords_per_s\": %.2f, \"GB_per_s\": %.1f}\n", mb,
+                   waves, recs / ms / 1e6, recs * 128 / ms / 1e6);
         }
         CHECK(hipFree(table));
     }
