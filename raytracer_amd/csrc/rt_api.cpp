@@ -911,11 +911,13 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     rt::SceneDev &D = db.dev;
     int rc;
     if ((rc = upload(db, dn, &D.nodes))) return rc;
-    // four-box records beside them for trees in global memory (RT355_QUADS=0: not, a test hook)
+    // four-box records beside them for trees in global memory.  RT355_QUADS=0: none, 2: walked by every
+    // launch without counters instead of by the later bounces only (LaunchShape::quads; a test hook)
     std::vector<float4> dq;
     uint32_t quad_need = 0;
     const char *quads_hook = getenv("RT355_QUADS");
-    bool quads = !lds_nodes && !(quads_hook && atoi(quads_hook) == 0) && build_quads(nodes, dq, quad_need);
+    const uint32_t quads_mode = quads_hook ? (uint32_t)atoi(quads_hook) : 1u;
+    bool quads = !lds_nodes && quads_mode != 0 && build_quads(nodes, dq, quad_need);
     if (quads && quad_need > rt::kSpillLevels) quads = false; // deeper than a lane's stack: two-box records only
     D.quads = nullptr;
     D.root_quad = 0;
@@ -1034,7 +1036,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     D.stack_lds = stack_lds;
     db.shape.slots = slots;
     db.shape.lds_nodes = lds_nodes;
-    db.shape.quads = quads;
+    db.shape.quads = quads ? (quads_mode >= 2 ? 2u : 1u) : 0u;
     // trees in global memory: a bounce is a trace launch and a shade launch (measured on the 11 M
     // primitive scene: +8 %); trees in LDS: one fused launch
     db.split_bounces = db.hooks.split >= 0 ? db.hooks.split != 0 : !lds_nodes;

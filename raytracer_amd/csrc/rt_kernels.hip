@@ -2683,7 +2683,7 @@ hipError_t launch_intersect(const SceneDev &S, const LaunchShape &L, const rt_ra
         else RT_LAUNCH((k_intersect<false, true>), blocks, threads, S, rays, n, hits, counters, cursor);
     } else {
         if (counters) RT_LAUNCH((k_intersect<true, false>), blocks, threads, S, rays, n, hits, counters, cursor);
-        else if (L.quads) RT_LAUNCH((k_intersect<false, false, true>), blocks, threads, S, rays, n, hits, counters, cursor);
+        else if (L.quads == 2) RT_LAUNCH((k_intersect<false, false, true>), blocks, threads, S, rays, n, hits, counters, cursor);
         else RT_LAUNCH((k_intersect<false, false>), blocks, threads, S, rays, n, hits, counters, cursor);
     }
     return hipGetLastError();
@@ -2697,7 +2697,7 @@ hipError_t launch_occluded(const SceneDev &S, const LaunchShape &L, const rt_ray
     if (blocks == 0) return hipSuccess;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) RT_LAUNCH((k_occluded<true>), blocks, threads, S, rays, n, out, cursor);
-    else if (L.quads) RT_LAUNCH((k_occluded<false, true>), blocks, threads, S, rays, n, out, cursor);
+    else if (L.quads == 2) RT_LAUNCH((k_occluded<false, true>), blocks, threads, S, rays, n, out, cursor);
     else RT_LAUNCH((k_occluded<false>), blocks, threads, S, rays, n, out, cursor);
     return hipGetLastError();
 }
@@ -2831,7 +2831,7 @@ hipError_t launch_trace(const SceneDev &S, const LaunchShape &L, const Queue &qi
         else RT_LAUNCH((k_trace<false, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
     } else {
         if (counters) RT_LAUNCH((k_trace<true, false>), L.grid, threads, S, qin, hits, counts, bounce, counters);
-        else if (L.quads) RT_LAUNCH((k_trace<false, false, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
+        else if (L.quads == 2 || (L.quads == 1 && bounce >= kQuadBounce)) RT_LAUNCH((k_trace<false, false, true>), L.grid, threads, S, qin, hits, counts, bounce, counters);
         else RT_LAUNCH((k_trace<false, false>), L.grid, threads, S, qin, hits, counts, bounce, counters);
     }
     return hipGetLastError();
@@ -2872,7 +2872,7 @@ hipError_t launch_shadow(const SceneDev &S, const LaunchShape &L, const ShadowQu
     const uint32_t threads = L.lds_nodes ? 1024 : kBlock;
     const size_t lds = lds_bytes(L.lds_nodes, S.n_pairs, S.stack_lds);
     if (L.lds_nodes) RT_LAUNCH((k_shadow<true>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
-    else if (L.quads) RT_LAUNCH((k_shadow<false, true>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
+    else if (L.quads == 2 || (L.quads == 1 && bounce >= kQuadBounce)) RT_LAUNCH((k_shadow<false, true>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
     else RT_LAUNCH((k_shadow<false>), L.grid, threads, S, q, shadow_counts, bounce, radiance);
     return hipGetLastError();
 }

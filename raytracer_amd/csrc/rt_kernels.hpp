@@ -102,7 +102,13 @@ struct LaunchShape {
     uint32_t slots;  // traversal stack entries a lane can need
     uint32_t grid;   // persistent workgroups
     bool lds_nodes;  // node array staged in LDS (1024-thread workgroups), else 256-thread workgroups
-    bool quads;      // trees in global memory: SceneDev::quads holds the four-box records the kernels without counters walk
+    // Trees in global memory, SceneDev::quads present: which launches without counters walk the
+    // four-box records.  They halve the dependent fetches and cost more arithmetic per level, which
+    // pays where rays are incoherent enough to miss the caches (measured on an 11 M primitive scene:
+    // camera rays and their first scatter -7 ... -11 %, every later bounce +17 ... +24 %, shuffled rays +13 %).
+    //   0 none; 1 the per-bounce trace and shadow launches from bounce kQuadBounce on;
+    //   2 those at every bounce and rt_intersect / rt_occluded too
+    uint32_t quads;
 };
 
 // Resident 256-thread workgroups per CU (= waves per SIMD) the kernels that read the tree
@@ -118,6 +124,7 @@ constexpr uint32_t kMaxEnclosing = 4;
 constexpr uint32_t kSpillLevels = 56;
 // 64-bit words of a scene's counter block: traversal counters 0-8, tail probe 28-31, profile builds 32-63
 constexpr uint32_t kCounterWords = 64;
+constexpr uint32_t kQuadBounce = 2;
 // Dynamic LDS of a trace workgroup (interior records for the LDS-resident shape + stacks).
 size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds);
 

@@ -66,3 +66,14 @@ def scene_with_hooks(monkeypatch, frozen, *args, **env):
     for k in env:
         monkeypatch.delenv(k)
     return g
+
+
+def set_node_source(monkeypatch, nodes):
+    """Test parameter -> library hooks, read when the scene is placed on the device.  "lds": the
+    library's own choice (small trees live in LDS); "global": two-box records in global memory, and
+    four-box records from the third bounce of a frame on, as for large scenes; "quads": global memory
+    with four-box records in every launch that has them (rt_intersect, rt_occluded, all bounces)."""
+    if nodes in ("global", "quads"):
+        monkeypatch.setenv("RT355_NODES", "global")
+    if nodes == "quads":
+        monkeypatch.setenv("RT355_QUADS", "2")

@@ -11,21 +11,20 @@ import pytest
 from raytracer_amd import abi, lib
 from raytracer_amd.scene import look_at, perspective_camera
 from tests import orc
-from tests.conftest import random_rays, scene_with_hooks
+from tests.conftest import random_rays, scene_with_hooks, set_node_source
 from tests.mixed import ball_scene, rays_inside
 from tests.test_parity_gpu import assert_hits_equal
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 @pytest.mark.parametrize("seed,max_prims,split", [(3, 4, abi.RT_SPLIT_SAH), (4, 1, abi.RT_SPLIT_HLBVH)] +
                          # a longer soak on request: RT355_SWEEP_EXTRA=<n> more seeds
                          [(s, 1 + s % 7, s % 4) for s in range(100, 100 + int(os.environ.get("RT355_SWEEP_EXTRA", "0")))])
 def test_rays_from_inside_the_balls(monkeypatch, nodes, seed, max_prims, split):
     import torch
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     sd, balls = ball_scene(seed=seed)
     fr = sd.freeze()
     g, o = lib.Scene(fr, max_prims, split), orc.OracleScene(fr, max_prims, split)
@@ -43,11 +42,10 @@ def test_rays_from_inside_the_balls(monkeypatch, nodes, seed, max_prims, split):
     assert_hits_equal(d_hits.cpu().numpy().view(abi.hit_dtype).reshape(-1), ref, "balls (counting)")
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 @pytest.mark.parametrize("loop_from", [None, 0, 2])
 def test_frames_through_the_balls(monkeypatch, nodes, loop_from):
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     sd, balls = ball_scene(seed=7)
     fr = sd.freeze()
     g = scene_with_hooks(monkeypatch, fr, **({} if loop_from is None else {"RT355_LOOP_FROM": loop_from}))

@@ -9,16 +9,16 @@ from raytracer_amd import abi, lib
 from tests import orc
 from tests.mixed import mixed_scene
 from tests.test_direct_light_cpu import floor_under_light, sphere_and_rect_lights
+from tests.conftest import set_node_source
 
 pytestmark = pytest.mark.gpu
 FLAG = abi.RT_RENDER_DIRECT_LIGHT
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 @pytest.mark.parametrize("name,w,h,spp,depth", [("cornell", 96, 96, 4, 50), ("week", 128, 96, 4, 50)])
 def test_direct_light_bit_exact(monkeypatch, scene_cache, nodes, name, w, h, spp, depth):
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     _, cam, fr = scene_cache(name)
     g, o = lib.Scene(fr), orc.OracleScene(fr)
     c = cam(w, h)
@@ -121,13 +121,12 @@ def test_emissive_sphere_beside_a_sampled_light():
     assert got.tobytes() == ref.tobytes()
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 def test_distant_light_bit_exact(monkeypatch, nodes):
     """LightSource "distant": alone (closed-form floor, see the CPU test), sharing the choice with
     a lamp, and on test.pbrt's scene with several sample batches and shards."""
     from tests.test_direct_light_cpu import floor_under_sun
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     w = h = 32
     for kw in (dict(), dict(lamp=True), dict(ball=False, towards=(1.0, -2.0, -0.5))):
         s, cam = floor_under_sun(**kw)

@@ -11,7 +11,7 @@ import pytest
 
 from raytracer_amd import abi, lib
 from tests import fp64_ref
-from tests.conftest import random_rays
+from tests.conftest import random_rays, set_node_source
 from tests.mixed import mixed_scene
 from tests.test_fp64_cpu import TOL, check_against_fp64, clipped_spheres_scene
 
@@ -47,10 +47,9 @@ def test_hip_matches_fp64_with_media(seed):
     assert ((g.does_intersect(rays) != 0) == (best["prim"] >= 0))[clear].all()
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 def test_hip_matches_fp64_on_clipped_transformed_spheres(monkeypatch, nodes):
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     fr = clipped_spheres_scene().freeze()
     g = lib.Scene(fr)
     rays = random_rays(30000, (-9, -9, -9), (9, 9, 9), 8, finite_fraction=0.1, axis_fraction=0.0)

@@ -10,7 +10,7 @@ import pytest
 
 from raytracer_amd import abi, lib
 from tests import orc
-from tests.conftest import scene_with_hooks, random_rays
+from tests.conftest import scene_with_hooks, random_rays, set_node_source
 from tests.mixed import mixed_scene
 
 pytestmark = pytest.mark.gpu
@@ -203,12 +203,11 @@ def test_full_size_properties(scene_cache):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 def test_streaming_paths(monkeypatch, nodes):
     """Rays enter and leave a wave one by one: every batch size around the 64-entry blocks,
     rays that miss the root box (lanes that never traverse), and both node sources."""
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     fr = mixed_scene(seed=9, n_each=60).freeze()
     g, o = lib.Scene(fr), orc.OracleScene(fr)
     wb = o.world_bound()
@@ -234,15 +233,14 @@ def test_streaming_paths(monkeypatch, nodes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 @pytest.mark.parametrize("direct", [False, True])
 def test_bounce_as_one_kernel_or_two(monkeypatch, scene_cache, nodes, direct):
     """A bounce is one fused launch (trees in LDS) or a trace launch and a shade launch (trees in
     global memory); RT355_SPLIT forces either form on either node source.  Frames, segment counts
     per bounce and traversal counters must not depend on the form, and equal the oracle's."""
     from raytracer_amd import abi
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     name, cam, fr = scene_cache("cornell" if direct else "week")
     flags = abi.RT_RENDER_DIRECT_LIGHT if direct else 0
     w, h, spp, depth = 96, 64, 5, 12
@@ -269,12 +267,11 @@ def _cam(w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 def test_stack_levels_beyond_lds(monkeypatch, nodes, scene_cache):
     """With only two stack levels in LDS most pushes land in the per-lane private array."""
     monkeypatch.setenv("RT355_STACK_LDS", "2")
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     name, cam, fr = scene_cache("week")
     g, o = lib.Scene(fr), orc.OracleScene(fr)
     wb = o.world_bound()
@@ -327,8 +324,7 @@ def test_one_launch_kernel_with_film_sampler_and_shards(monkeypatch, scene_cache
     kw = dict(seed=2, filter=FILTERS["mitchell"], sampler=abi.RT_SAMPLER_SOBOL)
     ref, rst = o.render(cam(w, h), orc.render_opts(w, h, spp, 30, **kw))
     for nodes in ("lds", "global"):
-        if nodes == "global":
-            monkeypatch.setenv("RT355_NODES", "global")
+        set_node_source(monkeypatch, nodes)
         for loop_from in (1, 3):
             g = scene_with_hooks(monkeypatch, fr, RT355_LOOP_FROM=loop_from)
             img, st = g.render(cam(w, h), lib.render_opts(w, h, spp, 30, max_paths=6 * 1024 * 2, **kw))
@@ -339,13 +335,12 @@ def test_one_launch_kernel_with_film_sampler_and_shards(monkeypatch, scene_cache
         g.close()
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 def test_one_launch_kernel_shares_sub_queues(monkeypatch, scene_cache, nodes):
     """A frame with more blocks per sub-queue than waves, so that blocks are claimed and a wave
     whose sub-queue is read out goes on with the others': same image and per-bounce segment
     counts as the oracle and as one launch per bounce, with the sharing on and off."""
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     _, cam, fr = scene_cache("week")
     o = orc.OracleScene(fr)
     w, h, spp, depth = 320, 200, 16, 50

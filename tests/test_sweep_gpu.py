@@ -10,7 +10,7 @@ import pytest
 from raytracer_amd import abi, lib
 from raytracer_amd.scene import look_at, perspective_camera
 from tests import orc
-from tests.conftest import random_rays
+from tests.conftest import random_rays, set_node_source
 from tests.mixed import mixed_scene
 from tests.test_parity_gpu import assert_hits_equal
 
@@ -64,6 +64,8 @@ def _drawn(seed):
 
 
 CASES += [_drawn(seed) for seed in range(109, 133)]
+# the same drawn cases that came out "global", once more with four-box records in every launch
+CASES += [c[:4] + ("quads",) + c[5:] for c in CASES if c[4] == "global"]
 # a longer soak on request: RT355_SWEEP_EXTRA=<n> draws n more cases
 CASES += [_drawn(seed) for seed in range(1000, 1000 + int(os.environ.get("RT355_SWEEP_EXTRA", "0")))]
 
@@ -71,8 +73,7 @@ CASES += [_drawn(seed) for seed in range(1000, 1000 + int(os.environ.get("RT355_
 @pytest.mark.parametrize("seed,n_each,max_prims,split,nodes,stack_lds", CASES)
 def test_seeded_case(monkeypatch, seed, n_each, max_prims, split, nodes, stack_lds):
     import torch
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     if stack_lds:
         monkeypatch.setenv("RT355_STACK_LDS", str(stack_lds))
     fr = mixed_scene(seed=seed, n_each=n_each, with_normals=bool(seed & 1), with_media=bool(seed & 2)).freeze()

@@ -45,12 +45,15 @@ def assert_same_hits(got, ref, what):
         len(got))
 
 
+@pytest.mark.parametrize("quads", [1, 2])
 @pytest.mark.parametrize("stack_lds", [None, 4])
 @pytest.mark.parametrize("split", [abi.RT_SPLIT_SAH, abi.RT_SPLIT_HLBVH])
-def test_reduced_synthetic_scene_bit_exact(monkeypatch, scene_cache, split, stack_lds):
+def test_reduced_synthetic_scene_bit_exact(monkeypatch, scene_cache, split, stack_lds, quads):
     import torch
     if stack_lds:
         monkeypatch.setenv("RT355_STACK_LDS", str(stack_lds))
+    # 1: four-box records from the third bounce on (the library's choice), 2: in every launch
+    monkeypatch.setenv("RT355_QUADS", str(quads))
     _, cam, fr = scene_cache("synthetic", grid=64, n_spheres=200_000)
     g, o = lib.Scene(fr, 4, split), orc.OracleScene(fr, 4, split)
     info = g.info()

@@ -9,7 +9,7 @@ import pytest
 
 from raytracer_amd import abi, lib
 from tests import orc
-from tests.conftest import random_rays
+from tests.conftest import random_rays, set_node_source
 
 pytestmark = pytest.mark.gpu
 
@@ -22,11 +22,10 @@ def _device_hits(g, entry, d_rays, n, stream):
     return d_hits.cpu().numpy()[:n].view(abi.hit_dtype).reshape(-1)
 
 
-@pytest.mark.parametrize("nodes", ["lds", "global"])
+@pytest.mark.parametrize("nodes", ["lds", "global", "quads"])
 def test_no_alloc_entry_point_matches_intersect_dev(monkeypatch, scene_cache, nodes):
     import torch
-    if nodes == "global":
-        monkeypatch.setenv("RT355_NODES", "global")
+    set_node_source(monkeypatch, nodes)
     _, cam, fr = scene_cache("week")
     g, o = lib.Scene(fr), orc.OracleScene(fr)
     wb = o.world_bound()
