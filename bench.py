@@ -15,7 +15,8 @@ frame: total work is fixed, so scaling is "strong".
 
 Extra objects on the JSON line:
   roofline     -- the bounce kernels (k_bounce: one launch per bounce while the
-                  queue is large; k_bounce_loop: one launch for all later bounces).
+                  queue is large; k_bounce_loop: one launch for all later bounces;
+                  trees in global memory: k_trace + k_shade per bounce).
                   `bound` names the resource that limits them and `achieved / peak /
                   frac` are of THAT resource:
                     week scene (tree in LDS): "valu" -- wave-level vector instructions
@@ -24,10 +25,11 @@ Extra objects on the JSON line:
                       the timed steps) against the issue rate tools/valu_peak.hip
                       measured on this chip; `frac_vs_guide_peak` is the same against
                       2 cycles per wave64 instruction;
-                    --config C5 (tree in global memory): "hbm" -- 64-byte requests that
-                      leave L2 per second against the rate tools/gather_peak.hip measured
-                      for dependent random 64-byte record reads from a table of the
-                      tree's size.
+                    --config C5 (tree in global memory; a bounce is k_trace + k_shade):
+                      "valu" as well since the trace walks 128-byte four-box records;
+                      `l2` holds the 64-byte requests that leave L2 per second against the
+                      rate tools/gather_peak.hip measured for dependent random reads of
+                      128-byte records from a table of the tree's size.
                   `algorithmic` is the reading the metric's definition asks for:
                   algorithmic bytes of all ray segments of a frame (traversal counters
                   of an untimed counting frame; identical to the oracle's) over the
@@ -63,9 +65,10 @@ RAY_BYTES, OUT_BYTES, NODE_BYTES = 32, 32, 32
 PRIM_BYTES = [16, 32, 36, 24, 24, 124, 32, 0]  # sphere, moving, triangle, rect, box, gsphere, medium
 # Vector-instruction issue: 256 CUs x 4 SIMDs; the guide's 2 cycles per wave64 instruction at 2.4 GHz
 GUIDE_ISSUE_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
-# Dependent random reads of 64-byte records from a table of the C5 tree's size (0.7 GB of records beside
-# 0.5 GB of other tables), 6 waves per SIMD: tools/gather_peak.hip, profiles/r03_gather_peak.jsonl
-GATHER_PEAK_GREC_S = 57.0
+# Dependent random reads of 128-byte records from a table of the size of the C5 tree's record tables
+# (0.7 GB of two-box and 0.7 GB of four-box records), 6 waves per SIMD: 65 G records/s = 130 G 64-byte
+# requests/s (64-byte records: 57 G/s).  tools/gather_peak.hip, profiles/r03_gather_peak.jsonl
+GATHER_PEAK_GREQ_S = 130.0
 
 
 def algorithmic_bytes(stats):
@@ -271,9 +274,9 @@ def main():
         alg_gbs = alg_bytes / frame_trace_s / 1e9 if trace_ms > 0 else 0.0
         lds_tree = args.config == "C3"
         roofline = {
-            "kernel": "k_bounce + k_bounce_loop",
-            "bound": "valu" if lds_tree else "hbm",
-            "achieved": None, "peak": None, "unit": "Ginst/s" if lds_tree else "Grequests/s", "frac": None,
+            "kernel": "k_bounce + k_bounce_loop" if lds_tree else "k_trace + k_shade (one pair per bounce)",
+            "bound": "valu",
+            "achieved": None, "peak": None, "unit": "Ginst/s", "frac": None,
             "traffic": None,
             "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
             # the reading the metric's definition asks for
@@ -286,10 +289,14 @@ def main():
                      "counters show vector-instruction issue as the limit, and achieved / peak / frac are wave-level "
                      "vector instructions per second against the rate measured on this chip (tools/valu_peak.hip)")
             if lds_tree else
-                    ("every interior step is a dependent fetch of a 64-byte record from a table far larger than the "
-                     "caches; achieved / peak / frac are 64-byte requests leaving L2 per second against the rate "
-                     "measured for such reads on this chip (tools/gather_peak.hip); `algorithmic` counts every node "
-                     "visit although the top of the tree is served by L1 and L2"),
+                    ("a bounce is a trace launch (k_trace) and a shade launch (k_shade); avg_launch_ms is the pair's.  "
+                     "The tree is far larger than the caches.  From the third bounce on the trace walks 128-byte "
+                     "records with four boxes, which the memory system delivers as fast as 64-byte ones, and the "
+                     "counters then show vector-instruction issue ahead of memory requests as the resource nearest "
+                     "its limit: achieved / peak / frac are wave-level vector instructions per second against the "
+                     "rate measured on this chip (tools/valu_peak.hip); `l2` has the 64-byte requests that leave L2 "
+                     "per second against the rate measured for dependent random reads of 128-byte records "
+                     "(tools/gather_peak.hip).  `algorithmic` counts every node visit of the reference's walk"),
         }
         out = {
             "metric": "Mrays/s", "value": round(segments / elapsed / 1e6, 2), "unit": "Mrays/s",
@@ -322,18 +329,18 @@ def main():
                         "guide_peak_ginst_s": round(GUIDE_ISSUE_PEAK_GINST_S, 1),
                         "active_lane_frac": v.get("active_lane_frac"), "peak_basis": v.get("peak_basis"),
                         "source": pmc.get("source", "profiles/" + os.path.basename(pmc_file))}
-                    if lds_tree:
-                        roofline.update(achieved=round(rate, 1), peak=v["peak_ginst_s"],
-                                        frac=round(rate / v["peak_ginst_s"], 4))
+                    roofline.update(achieved=round(rate, 1), peak=v["peak_ginst_s"],
+                                    frac=round(rate / v["peak_ginst_s"], 4))
                 g = pmc.get("l2_requests")
                 if g and not lds_tree:
                     rate = g["ea_read_requests_per_frame"] / frame_trace_s / 1e9
-                    roofline.update(achieved=round(rate, 2), peak=GATHER_PEAK_GREC_S,
-                                    frac=round(rate / GATHER_PEAK_GREC_S, 4))
                     roofline["l2"] = {"hit_rate": g.get("l2_hit_rate"),
                                       "requests_beyond_l2_per_segment": round(g["ea_read_requests_per_frame"] / max(counted.segments, 1), 2),
-                                      "peak_basis": "dependent random reads of 64-byte records, table of the tree's size, "
-                                                    "6 waves per SIMD (tools/gather_peak.hip, profiles/r03_gather_peak.jsonl)"}
+                                      "achieved_grequests_s": round(rate, 2), "peak_grequests_s": GATHER_PEAK_GREQ_S,
+                                      "frac": round(rate / GATHER_PEAK_GREQ_S, 4),
+                                      "peak_basis": "dependent random reads of 128-byte records (two 64-byte requests each) from "
+                                                    "a 1.4 GB table, 6 waves per SIMD (tools/gather_peak.hip, "
+                                                    "profiles/r03_gather_peak.jsonl)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["host"]["cpu_threads_used"] = cpu["cores"]

@@ -6,7 +6,7 @@
 set -u
 OUT=${1:-gpurun_out/profile}
 CFG=${2:-C3}
-if [ "$CFG" = C5 ]; then SPP=128; CUR=pmc_current_c5.json; LIMIT=420; RAW=--raw-fetch; else SPP=64; CUR=pmc_current.json; LIMIT=240; RAW=; fi
+if [ "$CFG" = C5 ]; then SPP=128; CUR=pmc_current_c5.json; LIMIT=420; RAW=--raw-fetch; KERNELS="k_trace<false;k_shade<"; else SPP=64; CUR=pmc_current.json; LIMIT=240; RAW=; KERNELS="k_bounce<false;k_bounce_loop<false"; fi
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -27,6 +27,6 @@ for P in "${PASSES[@]}"; do
   rc=$?; echo "pass $i rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 "$ROOT/$OUT/pass$i.log"; exit $rc; fi
 done
-python3 $ROOT/tools/summarize_pmc.py "$ROOT/$OUT" "k_bounce<false,k_bounce_loop<false" --current "$ROOT/$OUT/$CUR" --spp $SPP $RAW > "$ROOT/$OUT/pmc_summary.json"
+python3 $ROOT/tools/summarize_pmc.py "$ROOT/$OUT" "$KERNELS" --current "$ROOT/$OUT/$CUR" --spp $SPP $RAW > "$ROOT/$OUT/pmc_summary.json"
 cp "$ROOT/$OUT"/trace/*/*kernel_stats.csv "$ROOT/$OUT/kernel_stats.csv" 2>/dev/null || true
 echo "summaries: $OUT/pmc_summary.json $OUT/$CUR $OUT/kernel_stats.csv"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter CSVs per kernel and derives the ratios quoted in the
-design notes.  usage: summarize_pmc.py <dir> [kernel substrings, comma separated] [--current out.json --spp N]
+design notes.  usage: summarize_pmc.py <dir> [kernel substrings, separated by semicolons] [--current out.json --spp N]
 
 --current writes the file bench.py reads its roofline.traffic and roofline.valu from: the counters
 per frame, stamped with a hash of the kernel sources they were measured on (bench.py ignores the
@@ -18,8 +18,8 @@ import sys
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 root = args[0]
-match = args[1] if len(args) > 1 else "k_bounce<false,k_bounce_loop<false"  # comma separated substrings
-wanted = match.split(",")
+match = args[1] if len(args) > 1 else "k_bounce<false;k_bounce_loop<false"  # substrings (kernel names hold commas)
+wanted = match.split(";")
 traffic_out = sys.argv[sys.argv.index("--current") + 1] if "--current" in sys.argv else None
 spp = int(sys.argv[sys.argv.index("--spp") + 1]) if "--spp" in sys.argv else 64
 args = [a for a in args if a != traffic_out and a != str(spp)]
