@@ -1374,7 +1374,10 @@ RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
     float ww = w * w * (3.0f - 2.0f * w);
     const int32_t *px = S.perlin_perm, *py = S.perlin_perm + 256, *pz = S.perlin_perm + 512;
     float accum = 0.0f;
-    // rolled on purpose: noise is rare and must not set the kernel's register budget
+#ifndef RT_PERLIN
+#define RT_PERLIN 2
+#endif
+#if RT_PERLIN == 0
 #pragma unroll 1
     for (int di = 0; di < 2; di++)
 #pragma unroll 1
@@ -1390,6 +1393,40 @@ RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
                 float fk = dk ? ww : 1.0f - ww;
                 accum += fi * fj * fk * dt;
             }
+#else
+    // A noise lookup is a chain of dependent gathers (permutation entries, then gradient vectors):
+    // corner by corner it was sixteen round trips, and a turbulence sum makes seven lookups.  The
+    // six permutation entries come in one round trip and the gradient vectors of RT_PERLIN corners at a
+    // time in another.  The corners are still added in the order (di, dj, dk) = (0,0,0), (0,0,1),
+    // (0,1,0), ...; the outer loops stay rolled so that noise, which is rare, does not set the
+    // kernel's register budget.
+    const int pxi[2] = {px[i & 255], px[(i + 1) & 255]};
+    const int pyj[2] = {py[j & 255], py[(j + 1) & 255]};
+    const int pzk[2] = {pz[k & 255], pz[(k + 1) & 255]};
+    constexpr int kAtOnce = RT_PERLIN; // 2 or 4
+#pragma unroll 1
+    for (int first = 0; first < 8; first += kAtOnce) {
+        float c[kAtOnce][3];
+#pragma unroll
+        for (int q = 0; q < kAtOnce; q++) {
+            const int corner = first + q, di = corner >> 2, dj = (corner >> 1) & 1, dk = corner & 1;
+            const float *g = S.perlin_vec + 3 * ((di ? pxi[1] : pxi[0]) ^ (dj ? pyj[1] : pyj[0]) ^ (dk ? pzk[1] : pzk[0]));
+            c[q][0] = g[0];
+            c[q][1] = g[1];
+            c[q][2] = g[2];
+        }
+#pragma unroll
+        for (int q = 0; q < kAtOnce; q++) {
+            const int corner = first + q, di = corner >> 2, dj = (corner >> 1) & 1, dk = corner & 1;
+            const float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+            const float dt = c[q][0] * wx + c[q][1] * wy + c[q][2] * wz;
+            const float fi = di ? uu : 1.0f - uu;
+            const float fj = dj ? vv : 1.0f - vv;
+            const float fk = dk ? ww : 1.0f - ww;
+            accum += fi * fj * fk * dt;
+        }
+    }
+#endif
     return accum;
 }
 RT_DEV float perlin_turb(const SceneDev &S, v3 p) {
