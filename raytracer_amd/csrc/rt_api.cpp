@@ -910,6 +910,19 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     }
     rt::SceneDev &D = db.dev;
     int rc;
+    // trees in LDS (at most 32 k primitives): the record once per leaf entry, in leaf order (RT355_PLAIN_PER_ENTRY=0/1 overrides)
+    {
+        const char *hook = getenv("RT355_PLAIN_PER_ENTRY");
+        D.plain_per_entry = (hook ? atoi(hook) != 0 : lds_nodes) ? 1u : 0u;
+        if (D.plain_per_entry) {
+            std::vector<rt::PlainShade> per_entry(leaf.size());
+            for (size_t k = 0; k < leaf.size(); k++) {
+                memset(&per_entry[k], 0, sizeof per_entry[k]);
+                if (leaf[k].material < plain.size()) per_entry[k] = plain[leaf[k].material];
+            }
+            plain.swap(per_entry);
+        }
+    }
     if ((rc = upload(db, dn, &D.nodes))) return rc;
     // four-box records beside them for trees in global memory.  RT355_QUADS=0: none, 2: walked by every
     // launch without counters instead of by the later bounces only (LaunchShape::quads; a test hook)

@@ -126,12 +126,13 @@ struct SceneDev {
     const Medium *media;
     const rt_material *materials;
     const rt_texture *textures;
-    const PlainShade *plain;  // one per material
+    const PlainShade *plain;  // one per material, or (plain_per_entry) one per leaf entry
     const ImageDev *images;
     const float *perlin_vec;
     const int32_t *perlin_perm;
     const LightDev *lights;
     uint32_t n_lights;
+    uint32_t plain_per_entry; // `plain` is indexed by leaf slot instead of by material
     uint32_t n_nodes, n_prims; // n_nodes: LinearBVHNode count of the tree (0 = empty tree)
     // Media that enclose the scene are not in the tree: their entries follow the tree's
     // n_tree_prims primitives in `leaf`, and every ray tests them before it starts traversing.

@@ -1531,6 +1531,11 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     }
     bool alive = true;
     LeafPrim lp = S.leaf[L.best & ~kBestRare];
+    // Small scenes keep the plain shader's material record once per leaf entry, so that it is fetched beside
+    // the entry instead of after it (one dependent round trip less); large ones once per material,
+    // where a per-entry table would be a gather over hundreds of megabytes.
+    PlainShade ps;
+    if (PLAIN && S.plain_per_entry) ps = S.plain[L.best & ~kBestRare];
     Surf h;
     if (PLAIN) prim_finalize_plain(S, lp, L.ray, L.ray.t_max, L.a0, L.a1, L.a2, h);
     else prim_finalize(S, lp, L.ray, L.ray.t_max, L.a0, L.a1, L.a2, h);
@@ -1540,9 +1545,8 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     // The plain shader reads material and texture from one record per material (a load that
     // runs beside the geometry's); the general one follows the references.
     rt_material m;
-    PlainShade ps;
     if (PLAIN) {
-        ps = S.plain[lp.material];
+        if (!S.plain_per_entry) ps = S.plain[lp.material];
         m.kind = ps.material_kind;
         m.texture = 0;
         m.fuzz = ps.fuzz;
