@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "librt355.so")
 SOURCES = ["rt_kernels.hip", "rt_build_gpu.hip", "rt_api.cpp", "rt_bvh.cpp"]
-HEADERS = ["rt_device.hpp", "rt_kernels.hpp", "rt_bvh.hpp"]
+HEADERS = ["rt_device.hpp", "rt_kernels.hpp", "rt_bvh.hpp", "rt_probe.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function"]
 

@@ -743,7 +743,7 @@ int build_device(rt_scene &s, int device, DeviceBuffers &db) {
     const char *force = getenv("RT355_NODES"); // "global": override for experiments
     bool lds_nodes = false;
     uint32_t stack_lds = 0;
-    constexpr size_t kDump = 256; // where prefetches land (rt::lds_bytes adds it)
+    constexpr size_t kDump = 256; // slack (rt::lds_bytes adds it)
     if (n_pairs > 0 && n_pairs < 0x8000u && s.prims.size() < 0x8000u && (size_t)n_pairs * 64 + kDump < lds_cu) {
         const size_t room = lds_cu - (size_t)n_pairs * 64 - kDump;
         stack_lds = (uint32_t)std::min<size_t>(slots, room / (1024 * 6));

@@ -19,6 +19,7 @@
 
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
+#include "rt_probe.hpp" // PROF(...), opaque(), probe::double_*: measuring aids, all empty in the shipped build
 
 namespace rt {
 
@@ -85,7 +86,6 @@ struct TreeView {
     typename Shape<LDSN>::RefT *ref; // stack part in LDS: ref[level * kThreads], near[level * kThreads]
     float *near;
     uint32_t levels;     // stack levels kept in LDS
-    float *dump;         // 256 bytes behind the stacks where prefetches land (never read)
 };
 
 // Carves the dynamic LDS; with LDSN also stages the records (call from all threads).
@@ -112,26 +112,7 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
     v.ref = reinterpret_cast<typename Shape<LDSN>::RefT *>(reinterpret_cast<float *>(base) +
                                                             (size_t)S.stack_lds * kThreads) +
             threadIdx.x;
-    // behind the stacks: near (4 bytes) and ref (RefT) per level and thread
-    v.dump = reinterpret_cast<float *>(reinterpret_cast<char *>(base) +
-                                       (size_t)S.stack_lds * kThreads * (sizeof(float) + sizeof(typename Shape<LDSN>::RefT)));
     return v;
-}
-
-// Build with -DRT_PROFILE to have the counting kernels also time their phases
-// (shader clock) and tally lane occupancy; rt_render_dev prints the totals.
-#ifdef RT_PROFILE
-#define PROF(...) __VA_ARGS__
-#else
-#define PROF(...)
-#endif
-
-// Cost probes (-DRT_DOUBLE_SHADE / _PRIM / _SLAB / _PRETEST): the named piece runs a second time on
-// opaque copies of its inputs with its results thrown away, so that counter deltas between
-// builds measure that piece.  Never defined in the shipped library.
-RT_DEV float opaque(float x) {
-    asm volatile("" : "+v"(x));
-    return x;
 }
 
 struct Counters {
@@ -382,7 +363,15 @@ RT_DEV void pretest(const SceneDev &S, const Ray &ray, float &t_max, uint32_t &c
 RT_DEV uint32_t pretest_best(const SceneDev &S, uint32_t code, bool &resolved) {
     const uint32_t which = code & 0xffu, r = (code >> 8) & 0xffu;
     resolved = r != 0;
-    if (r != 0 && (r - 1u) % 3u != 2u) return S.balls[(r - 1u) / 3u].best[(r - 1u) % 3u];
+    if (r != 0 && (r - 1u) % 3u != 2u) {
+        // chosen among the few candidates, which are scalar values, instead of gathered with the lane's own index
+        uint32_t v = RT_MISS;
+        for (uint32_t k = 0; k < S.n_balls; k++) {
+            v = r - 1u == 3u * k ? S.balls[k].best[0] : v;
+            v = r - 1u == 3u * k + 1u ? S.balls[k].best[1] : v;
+        }
+        return v;
+    }
     if (which == 0) return RT_MISS;
     return (S.n_tree_prims + which - 1) | (((S.enclosing_rare >> (which - 1)) & 1u) ? kBestRare : 0u);
 }
@@ -666,17 +655,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                     }
                     if (COUNT) cnt.nodes += 2;
                     float t0, t1;
-#ifdef RT_DOUBLE_SLAB
-                    {
-                        float4 p0 = q0, p1 = q1, p2 = q2, p3 = q3;
-                        p0.x = opaque(p0.x); p1.x = opaque(p1.x); p2.x = opaque(p2.x); p3.x = opaque(p3.x);
-                        float u0, u1;
-                        bool g0 = slab(p0, p1, L.ray, inv, negx, negy, negz, u0);
-                        bool g1 = slab(p2, p3, L.ray, inv, negx, negy, negz, u1);
-                        float sink = (g0 ? u0 : 0.0f) + (g1 ? u1 : 0.0f);
-                        asm volatile("" ::"v"(sink));
-                    }
-#endif
+                    probe::double_slab(q0, q1, q2, q3, L.ray, inv, negx, negy, negz);
                     const bool h0 = slab(q0, q1, L.ray, inv, negx, negy, negz, t0);
                     const bool h1 = slab(q2, q3, L.ray, inv, negx, negy, negz, t1);
                     const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
@@ -686,19 +665,6 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                         push(neg ? r0 : r1, neg ? t0 : t1);
                         cur = neg ? r1 : r0;
                         need_pop = false;
-#ifdef RT_PREFETCH_FAR
-                        // The far child's record is asked for now, into a dump area in LDS that nobody
-                        // reads: when the entry is popped, dozens of steps later, its fetch finds the
-                        // line in L2 or the Infinity Cache instead of paying an HBM miss in the lane's
-                        // dependent chain.
-                        if constexpr (!LDSN) {
-                            const uint32_t far = neg ? r0 : r1;
-                            if ((far >> 31) == 0)
-                                __builtin_amdgcn_global_load_lds(
-                                    (const __attribute__((address_space(1))) void *)(S.nodes + 4 * (size_t)far),
-                                    (__attribute__((address_space(3))) void *)tv.dump, 4, 0, RT_PREFETCH_FAR);
-                        }
-#endif
                     } else if (h0 || h1) {
                         cur = h0 ? r0 : r1;
                         need_pop = false;
@@ -728,16 +694,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
 #pragma unroll
                         for (uint32_t q = 0; q < 8; q++) cnt.prims[q] += (k == q) ? 1u : 0u;
                     }
-#ifdef RT_DOUBLE_PRIM
-                    {
-                        Ray r2 = L.ray;
-                        r2.o.x = opaque(r2.o.x);
-                        float t2 = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-                        bool g = prim_test(S, lp, r2, inv, t2, c0, c1, c2);
-                        float sink = g ? t2 + c0 + c1 + c2 : 0.0f;
-                        asm volatile("" ::"v"(sink));
-                    }
-#endif
+                    probe::double_prim(S, lp, L.ray, inv);
                     // One component of the direction goes through an opaque copy inside the loop:
                     // otherwise everything a kind derives from the ray alone (the triangle's
                     // permutation and shear with three divisions, most of the medium's hash, the
@@ -1302,17 +1259,7 @@ RT_DEV void queue_push(const SceneDev &S, const Queue &q, size_t slot, const Ray
         uint32_t code;
         Ray fresh = r;
         fresh.t_max = kInf; // every queued ray starts unbounded
-#ifdef RT_DOUBLE_PRETEST
-        {
-            Ray again = fresh;
-            again.o.x = opaque(again.o.x);
-            float t2;
-            uint32_t c2;
-            pretest(S, again, t2, c2);
-            float sink = t2 + __uint_as_float(c2);
-            asm volatile("" ::"v"(sink));
-        }
-#endif
+        probe::double_pretest(S, fresh);
         pretest(S, fresh, t_max, code);
         q.e[slot] = make_uint2(__float_as_uint(t_max), code);
     }
@@ -1374,36 +1321,16 @@ RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
     float ww = w * w * (3.0f - 2.0f * w);
     const int32_t *px = S.perlin_perm, *py = S.perlin_perm + 256, *pz = S.perlin_perm + 512;
     float accum = 0.0f;
-#ifndef RT_PERLIN
-#define RT_PERLIN 2
-#endif
-#if RT_PERLIN == 0
-#pragma unroll 1
-    for (int di = 0; di < 2; di++)
-#pragma unroll 1
-        for (int dj = 0; dj < 2; dj++)
-#pragma unroll 1
-            for (int dk = 0; dk < 2; dk++) {
-                int idx = px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255];
-                const float *c = S.perlin_vec + 3 * idx;
-                float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
-                float dt = c[0] * wx + c[1] * wy + c[2] * wz;
-                float fi = di ? uu : 1.0f - uu;
-                float fj = dj ? vv : 1.0f - vv;
-                float fk = dk ? ww : 1.0f - ww;
-                accum += fi * fj * fk * dt;
-            }
-#else
     // A noise lookup is a chain of dependent gathers (permutation entries, then gradient vectors):
     // corner by corner it was sixteen round trips, and a turbulence sum makes seven lookups.  The
-    // six permutation entries come in one round trip and the gradient vectors of RT_PERLIN corners at a
-    // time in another.  The corners are still added in the order (di, dj, dk) = (0,0,0), (0,0,1),
-    // (0,1,0), ...; the outer loops stay rolled so that noise, which is rare, does not set the
-    // kernel's register budget.
+    // six permutation entries come in one round trip and the gradient vectors of two corners at a
+    // time in another (four at a time gained nothing and cost other scenes registers).  The corners
+    // are still added in the order (di, dj, dk) = (0,0,0), (0,0,1), (0,1,0), ...; the loop over the
+    // pairs stays rolled so that noise, which is rare, does not set the kernel's register budget.
     const int pxi[2] = {px[i & 255], px[(i + 1) & 255]};
     const int pyj[2] = {py[j & 255], py[(j + 1) & 255]};
     const int pzk[2] = {pz[k & 255], pz[(k + 1) & 255]};
-    constexpr int kAtOnce = RT_PERLIN; // 2 or 4
+    constexpr int kAtOnce = 2;
 #pragma unroll 1
     for (int first = 0; first < 8; first += kAtOnce) {
         float c[kAtOnce][3];
@@ -1426,7 +1353,6 @@ RT_DEV float perlin_noise(const SceneDev &S, v3 p) {
             accum += fi * fj * fk * dt;
         }
     }
-#endif
     return accum;
 }
 RT_DEV float perlin_turb(const SceneDev &S, v3 p) {
@@ -1559,15 +1485,7 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
     // (Lambertian, metallic, isotropic).  Per path the RNG draws stay in
     // the same order as when each material is evaluated on its own.
     v3 tex = mk(1.0f, 1.0f, 1.0f), rs = mk(0.0f, 0.0f, 0.0f);
-#ifdef RT_DOUBLE_RS
-    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC) {
-        Rng r2 = rng;
-        r2.inc = (uint64_t)__float_as_uint(opaque(__uint_as_float((uint32_t)r2.inc))) | (r2.inc & 0xffffffff00000000ull);
-        v3 q = random_in_unit_sphere(r2);
-        float sink = q.x + q.y + q.z;
-        asm volatile("" ::"v"(sink));
-    }
-#endif
+    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC) probe::double_unit_sphere(rng);
     if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METALLIC || m.kind == RT_MAT_ISOTROPIC)
         rs = random_in_unit_sphere(rng);
     if (m.kind != RT_MAT_DIELECTRIC) {
@@ -1668,23 +1586,6 @@ RT_DEV bool shade(const SceneDev &S, Lane &L, v3 &beta, Rng &rng, uint32_t local
 // rather than whenever one ray of a wave does.  The lanes' traversal state is
 // written to memory around a shading batch and read back after it, so shading and
 // traversal do not compete for registers.
-// Asks for the lines of a queue block (64 entries from `first`) without waiting for them: the loads
-// land in a dump area in LDS that nobody reads.  A wave claims its next block a whole feed turn
-// before it hands out that block's rays, and the queue was written by the launch before, so without
-// this every hand-out and every shading batch waits for memory the wave could have asked for long ago.
-RT_DEV void prefetch_block(const Queue &q, size_t first, bool with_e, float *dump) {
-    const uint32_t lane = threadIdx.x & 63;
-    auto touch = [&](const void *p) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                         (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
-    };
-    touch(q.a + first + lane);
-    touch(q.b + first + lane);
-    touch(q.c + first + lane);
-    touch(q.d + first + lane);
-    if (with_e) touch(q.e + first + lane);
-}
-
 template <bool NEE>
 struct BounceFeed {
     static constexpr bool kPretested = true;
@@ -1706,7 +1607,6 @@ struct BounceFeed {
     uint32_t *stail;
     size_t shadow_base; // first entry of the shadow sub-queue written (its own capacity, not qout's)
     uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
-    float *dump = nullptr; // where prefetches land (LDS)
     PROF(unsigned long long prof_shade = 0;) // cycles in shading batches incl. state save and reload
     PROF(unsigned long long prof_take = 0; unsigned long long prof_load = 0; unsigned long long prof_park = 0;)
     PROF(unsigned long long prof_b[16] = {};)
@@ -1777,7 +1677,9 @@ struct BounceFeed {
             rng.state = ((uint64_t)qd.x << 32) | __float_as_uint(qc.w);
             rng.inc = (((seed << 32) + gpath) << 1) | 1u;
 #ifdef RT_DOUBLE_SHADE
-            {
+            // cost probe (rt_probe.hpp); frames without direct lighting only: with it `local` still carries
+            // a flag in bit 31 here and radiance is accumulated, so a second run would write out of bounds
+            if constexpr (!NEE) {
                 Lane P2 = P;
                 P2.ray.o.x = opaque(P2.ray.o.x);
                 v3 beta2 = beta;
@@ -1877,14 +1779,7 @@ struct BounceFeed {
         }
         PROF(const unsigned long long prof_t1 = __builtin_amdgcn_s_memtime(); prof_shade += prof_t1 - prof_t0;)
         // next rays
-#ifdef RT_PREFETCH_QUEUE
-        const uint32_t blk_before = blocks.blk;
-#endif
         const uint32_t next = blocks.take(free);
-#ifdef RT_PREFETCH_QUEUE
-        if (blocks.blk != blk_before && blocks.more())
-            prefetch_block(qin, in_base + blocks.base + blocks.blk, (S.n_enclosing | S.n_balls) != 0, dump);
-#endif
         PROF(const unsigned long long prof_t2 = __builtin_amdgcn_s_memtime(); prof_take += prof_t2 - prof_t1;)
         bool fresh = false;
         if (free) {
@@ -1965,7 +1860,6 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                     reinterpret_cast<uint32_t *>(mine + 2 * kParkSlots * 24), {0u, 0u}, 0u, sq,
                     NEE ? scounts + ((size_t)bounce * kShards + shard) * kCountStride : nullptr,
                     (size_t)shard * sq.cap};
-    feed.dump = tv.dump;
     // camera rays of neighbouring pixels take about equally long, so a wave's 64 finish almost
     // together and refilling in between only adds turns; scattered rays do not
     trace_stream<false, COUNT, LDSN, false>(S, tv, feed, cnt, bounce == 0 ? primary_refill_lanes_of<LDSN>() : (LDSN ? kRefillLanes : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL));
@@ -2241,7 +2135,6 @@ struct LoopFeed {
     uint32_t parked[2];
     uint32_t ring_head, ring_count, turns, turn_limit;
     uint32_t code = 0; // what the producer of the ray a lane just received found out (pretest)
-    float *dump = nullptr; // where prefetches land (LDS)
     Counters *cnt = nullptr; // counting launches: where segments shaded without a traversal are counted
 #ifdef RT_TAIL_PROBE
     unsigned long long probe_dry = 0; // clock when this wave first found the queue read out
@@ -2441,14 +2334,7 @@ struct LoopFeed {
         const uint32_t rank = lane_rank(want);
         const uint32_t from_ring = min((uint32_t)__popcll(want), ring_count);
         const bool ring_lane = free && rank < from_ring;
-#ifdef RT_PREFETCH_QUEUE
-        const uint32_t blk_before = blocks.blk, base_before = blocks.base;
-#endif
         const uint32_t next = blocks.take(free && !ring_lane);
-#ifdef RT_PREFETCH_QUEUE
-        if ((blocks.blk != blk_before || blocks.base != base_before) && blocks.more())
-            prefetch_block(qin, in_base + blocks.base + blocks.blk, (S.n_enclosing | S.n_balls) != 0, dump);
-#endif
         bool fresh = false;
         if (free) {
             L.has_ray = false;
@@ -2566,7 +2452,6 @@ __global__ __launch_bounds__(Shape<LDSN>::kThreads, Shape<LDSN>::kWaves) void k_
                   reinterpret_cast<uint32_t *>(mine + kLoopParkBytes + kLoopLaneBytes + kLoopRingBytes),
                   {0u, 0u}, 0u, 0u, 0u, turn_limit};
     if (COUNT) feed.cnt = &cnt;
-    feed.dump = tv.dump;
     feed.blocks.start();
     trace_stream<false, COUNT, LDSN, false>(S, tv, feed, cnt, LDSN ? (uint32_t)RT_LOOP_REFILL_LANES : (uint32_t)RT_BOUNCE_REFILL_LANES_GLOBAL);
     if (COUNT) flush_counters(cnt, counters);
@@ -2698,7 +2583,7 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(float4 *rgba, size_t n)
 // lane), preceded by the interior records for the LDS-resident shape
 size_t lds_bytes(bool lds_nodes, uint32_t n_pairs, uint32_t stack_lds) {
     return (lds_nodes ? (size_t)n_pairs * 64 + (size_t)stack_lds * 1024 * (sizeof(float) + sizeof(uint16_t))
-                      : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t))) + 256; // + the prefetch dump
+                      : (size_t)stack_lds * kBlock * (sizeof(float) + sizeof(uint32_t))) + 256; // + slack
 }
 
 template <class K>
