@@ -28,8 +28,12 @@ fetch_factor = 1 if "--raw-fetch" in sys.argv else 2
 tot = collections.defaultdict(float)
 disp = collections.defaultdict(set)
 for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True)):
-    for r in csv.DictReader(open(f)):
-        if not any(w in r["Kernel_Name"] for w in wanted):
+    rows = list(csv.DictReader(open(f)))
+    # Kernels without a counting variant (k_shade) also run in the untimed counting frame that comes first:
+    # only dispatches from the first one of the first pattern on belong to the measured frame.
+    first = min((int(r["Dispatch_Id"]) for r in rows if wanted[0] in r["Kernel_Name"]), default=0)
+    for r in rows:
+        if not any(w in r["Kernel_Name"] for w in wanted) or int(r["Dispatch_Id"]) < first:
             continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"])
         disp[r["Counter_Name"]].add(r["Dispatch_Id"])
