@@ -436,7 +436,11 @@ int rt_generate_rays(const rt_camera *cam, const rt_render_opts *opts, uint64_t 
  * (FilmTile::add_sample, film.rs:281-328): a sample at raster position p adds
  * w * L and w to every pixel within the filter radius of p - 0.5, w from the
  * filter table; a shard adds only its own tiles' samples, so with several
- * shards pass RT_RENDER_RAW_FILM, sum the buffers and call rt_film_resolve_dev. */
+ * shards pass RT_RENDER_RAW_FILM, sum the buffers and call rt_film_resolve_dev.
+ * rt_render_dev with stats == NULL only enqueues the frame on `stream` and returns without waiting
+ * (what follows on the stream, e.g. a collective, needs no host round trip); an error the kernels flag
+ * in such a frame is reported by the next render call on that device.  With stats it waits for the
+ * frame and fills them. */
 int rt_render(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts, float *rgba_out,
               rt_stats *stats, int device);
 int rt_render_dev(rt_scene *scene, const rt_camera *cam, const rt_render_opts *opts,
