@@ -597,6 +597,15 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             if (n_hold >= leaf_lanes) break;
             if (can_refill && 64u - n_step - n_hold >= refill_lanes) break;
             PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
+            // Several steps per head count: the ballots, counts and branches above are a tenth of a step's
+            // instructions, and a lane that reaches a leaf a step or two before the wave looks again loses
+            // less than that (measured: 2 steps +1.2 %, 3 +1.8 %, 4-8 the same as 3).
+#ifndef RT_STEPS_PER_CHECK
+#define RT_STEPS_PER_CHECK 3
+#endif
+#pragma unroll 1
+            for (int rep = 0; rep < RT_STEPS_PER_CHECK; rep++) {
+            const bool stepping = (cur >> 31) == 0; // (shadows the head count's: a lane may have reached a leaf since)
             if (WIDE && stepping && !exact) {
                 const float4 *q = S.quads + 8 * (size_t)cur;
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
@@ -671,6 +680,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                     }
                 }
                 if (need_pop) cur = pop();
+            }
             }
         }
         PROF(if (COUNT) {
