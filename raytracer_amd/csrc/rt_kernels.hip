@@ -16,6 +16,7 @@
 // serialising on one word.  The wave count is a multiple of kShards and
 // every kShards consecutive waves cover all sub-queues (shard_of_wave).
 #include <mutex>
+#include <type_traits>
 
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
@@ -100,6 +101,12 @@ RT_DEV TreeView<LDSN> tree_view(const SceneDev &S) {
         const uint32_t n = S.n_pairs;
         for (uint32_t i = threadIdx.x; i < 4 * n; i += blockDim.x) { // a launch may bring fewer threads
             float4 x = S.nodes[i]; // record i / 4, quarter i % 4
+            // The two child references (.w of quarters 0 and 1) get a copy of their leaf flag in bit 15:
+            // their low half is then the 16-bit stack entry as it stands (see push and pop).
+            if ((i & 2u) == 0) {
+                const uint32_t r = __float_as_uint(x.w);
+                x.w = __uint_as_float(r | (r >> 16));
+            }
             base[(i & 3u) * n + (i >> 2)] = x;
         }
         __syncthreads();
@@ -438,6 +445,8 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
     constexpr int kStride = Shape<LDSN>::kThreads;
     constexpr uint32_t leaf_lanes = LDSN ? kLeafLanes : (uint32_t)RT_LEAF_LANES_GLOBAL;
     using RefT = typename Shape<LDSN>::RefT;
+    using StackT = typename std::conditional<LDSN, int16_t, uint32_t>::type;
+    constexpr uint32_t kLeafIndex = LDSN ? 0x7fffu : ~kLeafRef;
     RefT *const s_ref = tv.ref;
     float *const s_near = tv.near;
     const uint32_t levels = tv.levels;
@@ -454,14 +463,14 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
     L.ray.t_max = L.ray.time = 0.0f;
     inv = mk(0.0f, 0.0f, 0.0f);
     bool negx = false, negy = false, negz = false;
+    uint32_t negbits = 0; // LDSN: the same three as bits 0-2, one shift picks the bit of a record's split axis
     bool exact = false; // WIDE: this lane's ray walks the two-box records
     sp = 0;
     cur = kNone;
 
     auto push = [&](uint32_t r, float t) {
         if (sp < levels) {
-            if constexpr (LDSN) s_ref[sp * kStride] = (RefT)((r & 0x7fffu) | ((r >> 31) << 15));
-            else s_ref[sp * kStride] = r;
+            s_ref[sp * kStride] = (RefT)r; // LDSN: the low half already is the entry (tree_view)
             s_near[sp * kStride] = t;
         } else {
             spill_ref[sp - levels] = r;
@@ -477,11 +486,12 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             // the LDS read is unconditional (clamped level) and the private array is read in
             // its own branch: two address spaces behind one selected pointer would turn both
             // into slow generic loads
-            const uint32_t level = sp < levels ? sp : levels - 1;
-            uint32_t e = s_ref[level * kStride];
+            const uint32_t level = min(sp, levels - 1);
+            // LDSN: a 16-bit entry is read sign-extended: a leaf comes back as 0xFFFF8000 | first primitive
+            // (bit 31 set as in a record's reference; the leaf round masks the index to 15 bits)
+            uint32_t e = (uint32_t)(int32_t)(StackT)s_ref[level * kStride];
             float t = s_near[level * kStride];
             asm volatile("" : "+v"(e), "+v"(t)); // keeps both LDS reads DS instructions (see above)
-            if constexpr (LDSN) e = (e & 0x7fffu) | ((e & 0x8000u) << 16);
             if (sp >= levels) {
                 e = spill_ref[sp - levels];
                 t = spill_near[sp - levels];
@@ -571,6 +581,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                 negx = inv.x < 0.0f;
                 negy = inv.y < 0.0f;
                 negz = inv.z < 0.0f;
+                if constexpr (LDSN) negbits = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
                 PROF(if (COUNT) {
                     const unsigned long long t = __builtin_amdgcn_s_memtime();
                     cnt.p[8] += t - tp;
@@ -669,7 +680,11 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
                     const bool h1 = slab(q2, q3, L.ray, inv, negx, negy, negz, t1);
                     const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
                     const uint32_t axis = __float_as_uint(q2.w);
-                    const bool neg = axis == 0 ? negx : (axis == 1 ? negy : negz); // second child is nearer
+                    // second child is nearer.  One shift of the three signs as bits is 7 instructions shorter than
+                    // selecting among the lane masks; the 80-register shape pays more for the register that
+                    // holds the bits (measured: tree in LDS +0.4 %, tree in global memory -3.8 %).
+                    const bool neg = LDSN ? ((negbits >> axis) & 1u) != 0
+                                          : (axis == 0 ? negx : (axis == 1 ? negy : negz));
                     if (h0 && h1) {
                         push(neg ? r0 : r1, neg ? t0 : t1);
                         cur = neg ? r1 : r0;
@@ -695,7 +710,7 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             PROF(uint32_t my_iters = 0;)
             if (holding) {
                 bool stop = false;
-                for (uint32_t i = cur & ~kLeafRef;; i++) {
+                for (uint32_t i = cur & kLeafIndex;; i++) {
                     PROF(my_iters++;)
                     LeafPrim lp = S.leaf[i];
                     float t, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
