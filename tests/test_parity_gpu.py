@@ -285,6 +285,44 @@ def test_stack_levels_beyond_lds(monkeypatch, nodes, scene_cache):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stack_lds", [0, 2])
+def test_tree_in_lds_with_the_most_primitives_it_takes(monkeypatch, stack_lds):
+    """32 767 primitives is the most a tree traversed from LDS may index (15-bit leaf references,
+    16-bit stack entries read back sign-extended).  129 groups of up to 255 concentric spheres make
+    a few hundred large leaves (centroids that differ by rounding only), so the records fit in LDS
+    while the leaf references run up to the top of the 15 bits."""
+    from raytracer_amd.scene import SceneData, look_at, perspective_camera
+    if stack_lds:
+        monkeypatch.setenv("RT355_STACK_LDS", str(stack_lds))
+    rng = np.random.default_rng(5)
+    n = 0x7fff
+    centres = np.repeat(rng.uniform(-20, 20, (129, 3)), 255, axis=0)[:n]
+    sd = SceneData(background=(0.6, 0.7, 0.9))
+    grey = sd.lambertian((0.6, 0.6, 0.6))
+    sd.add_sphere_block(centres, rng.uniform(0.05, 2.0, n), grey)
+    fr = sd.freeze()
+    g, o = lib.Scene(fr, 4, abi.RT_SPLIT_SAH), orc.OracleScene(fr, 4, abi.RT_SPLIT_SAH)
+    assert g.info().n_prims == n and g.info().n_nodes < 2000  # 64 KB of two-child records at most
+    assert g.nodes().tobytes() == o.nodes().tobytes()
+    wb = o.world_bound()
+    rays = random_rays(40000, wb[:3], wb[3:], 11)
+    ref, ref_counters = o.intersect(rays, counters=True)
+    assert_hits_equal(g.intersect(rays), ref, "32767 primitives")
+    hit = ref["prim"] != 0xffffffff
+    assert o.prim_order()[-200:].min() < 0x7fff and np.isin(ref["prim"][hit], o.prim_order()[-2000:]).any()  # the last leaves are reached
+    assert (g.does_intersect(rays) == o.occluded(rays)).all()
+    import torch
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_hits = torch.empty((len(rays), 8), dtype=torch.float32, device="cuda")
+    counters = g.intersect_count(d_rays.data_ptr(), len(rays), d_hits.data_ptr())
+    assert (counters == ref_counters).all()
+    cam = perspective_camera(64, 48, 60.0, look_at((0.0, 5.0, 45.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)))
+    img, st = g.render(cam, lib.render_opts(64, 48, 2, 8, seed=3))
+    ref_img, rst = o.render(cam, orc.render_opts(64, 48, 2, 8, seed=3))
+    assert img.tobytes() == ref_img.tobytes() and st.segments == rst.segments
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene_name", ["week", "cornell", "random"])
 @pytest.mark.parametrize("loop_from", [0, 1, 4])
 def test_paths_followed_in_one_launch(monkeypatch, scene_cache, scene_name, loop_from):
