@@ -605,14 +605,25 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             if (m_step == 0) break;
             const uint32_t n_step = (uint32_t)__popcll(m_step);
             const uint32_t n_hold = (uint32_t)__popcll(__ballot(!stepping && cur != kNone));
+            // A leaf round is due when leaf_lanes lanes hold a leaf -- or 4 / RT_LEAF_SHARE of the lanes
+            // that have a ray at all: a wave with 30 rays left never gets to 32 holders, and without
+            // this rule its holders waited until the last stepping lane had reached a leaf, every time
+            // (at the end of a launch every wave is such a wave).  Measured on the headline frame and
+            // its eighth: share 4/6 ... 4/8 +1.0 % and -4 %, 4/5 +0.3 %, 4/12 -0.9 %; only once the
+            // queue is read out: nothing.
+#ifndef RT_LEAF_SHARE
+#define RT_LEAF_SHARE 7
+#endif
             if (n_hold >= leaf_lanes) break;
+            if (n_hold != 0 && n_hold * (uint32_t)RT_LEAF_SHARE >= (n_step + n_hold) * 4u) break;
             if (can_refill && 64u - n_step - n_hold >= refill_lanes) break;
             PROF(if (COUNT) { cnt.p[0]++; cnt.p[1] += stepping ? 1 : 0; })
             // Several steps per head count: the ballots, counts and branches above are a tenth of a step's
             // instructions, and a lane that reaches a leaf a step or two before the wave looks again loses
-            // less than that (measured: 2 steps +1.2 %, 3 +1.8 %, 4-8 the same as 3).
+            // less than that (measured: 2 steps +1.2 %, 3 +1.8 %, 4-8 the same as 3; with the share rule
+            // for leaf rounds above 4, 6 and 8 are another 0.5 % ahead of 3).
 #ifndef RT_STEPS_PER_CHECK
-#define RT_STEPS_PER_CHECK 3
+#define RT_STEPS_PER_CHECK 6
 #endif
 #pragma unroll 1
             for (int rep = 0; rep < RT_STEPS_PER_CHECK; rep++) {
@@ -703,10 +714,13 @@ RT_DEV void trace_stream(const SceneDev &S, const TreeView<LDSN> &tv, Feed &feed
             cnt.p[5] += t - tp;
             tp = t;
         })
-        // leaf round, bvh.rs:763-776: when enough lanes hold a leaf or nobody can step
+        // leaf round, bvh.rs:763-776: when enough lanes hold a leaf (the step loop's rule; nobody
+        // stepping is its case of all the lanes with a ray holding one)
         const bool holding = (cur >> 31) != 0 && cur != kNone;
         const uint32_t n_hold = (uint32_t)__popcll(__ballot(holding));
-        if (n_hold >= leaf_lanes || (n_hold != 0 && __ballot((cur >> 31) == 0) == 0)) {
+        const uint32_t n_step_left = (uint32_t)__popcll(__ballot((cur >> 31) == 0));
+        if (n_hold != 0 &&
+            (n_hold >= leaf_lanes || n_hold * (uint32_t)RT_LEAF_SHARE >= (n_step_left + n_hold) * 4u)) {
             PROF(uint32_t my_iters = 0;)
             if (holding) {
                 bool stop = false;
