@@ -1789,7 +1789,7 @@ int rt_render_dev(rt_scene *s, const rt_camera *cam, const rt_render_opts *o, fl
     // on the device (DeviceBuffers::Hooks).
     const DeviceBuffers::Hooks &hooks = db->hooks;
     const uint32_t loop_from = hooks.loop_from;
-    const uint64_t loop_below = hooks.loop_below_set ? hooks.loop_below : (db->shape.lds_nodes ? (8u << 20) : (2u << 20));
+    const uint64_t loop_below = hooks.loop_below_set ? hooks.loop_below : (db->shape.lds_nodes ? (12u << 20) : (2u << 20));
     const bool loop_steal = hooks.loop_steal;
     const uint32_t turn_limit = hooks.turn_limit;
     const bool want_counters = (o->flags & RT_RENDER_COUNTERS) != 0;
