@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of library variants on the large scene at an eighth of its samples.  usage: tools/ab_c5only.sh tag1 tag2 ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for T in "$@"; do
   export RT355_LIB=$ROOT/variants/librt355_$T.so
