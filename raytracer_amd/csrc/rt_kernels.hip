@@ -256,23 +256,37 @@ struct Blocks {
     RT_DEV void start() {
         if (cursor && sizes && blk >= n) claim();
     }
-    // Hands the next unread entries to the lanes that want one, in lane order; kNone
-    // for a lane that gets none (the current block is used up first, so some lanes
-    // may have to ask again).
+    RT_DEV void next_block() {
+        if (cursor) {
+            claim();
+        } else {
+            blk += stride;
+            off = 0;
+        }
+    }
+    // Hands the next unread entries to the lanes that want one, in lane order; kNone for a lane
+    // that gets none.  When the current block runs out the rest of the lanes are served from the
+    // next one in the same call: a block of 64 ends in the middle of two refills out of three,
+    // and a refill that brings a handful of rays is followed by another turn at once.
     RT_DEV uint32_t take(bool want) {
         const uint64_t m = __ballot(want);
+        const uint32_t n_want = (uint32_t)__popcll(m);
         const uint32_t len = blk < n ? min(64u, n - blk) : 0u;
         const uint32_t avail = len - off;
         const uint32_t rank = lane_rank(m);
-        const uint32_t idx = (want && rank < avail) ? base + blk + off + rank : kNone;
-        off += min((uint32_t)__popcll(m), avail);
+        uint32_t idx = (want && rank < avail) ? base + blk + off + rank : kNone;
+        off += min(n_want, avail);
         if (len != 0 && off >= len) {
-            if (cursor) {
-                claim();
-            } else {
-                blk += stride;
-                off = 0;
+            next_block();
+#ifndef RT_TAKE_ONE_BLOCK
+            if (n_want > avail) {
+                const uint32_t len2 = blk < n ? min(64u, n - blk) : 0u;
+                const uint32_t more = min(n_want - avail, len2);
+                if (want && rank >= avail && rank - avail < more) idx = base + blk + (rank - avail);
+                off = more;
+                if (len2 != 0 && off >= len2) next_block();
             }
+#endif
         }
         return idx;
     }
